@@ -1,0 +1,158 @@
+"""Pins oracle/ (the CPU restatement) against the committed golden fixtures, i.e. against the reference's own
+differential tests and known-answer tests (see tests/golden/gen_golden.py for what each fixture restates)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def qp_from(case):
+    cons = case["cons"]
+    return orc.QP(G=np.array(case["G"]).reshape(case["n"], case["n"]), c=case["c"],
+                  A_eq=np.array(case["A_eq"]).reshape(case["k"], case["n"]), b_eq=case["b_eq"],
+                  cons_var=[c[0] for c in cons], cons_a=[c[1] for c in cons], cons_b=[c[2] for c in cons])
+
+
+@pytest.mark.parametrize("case", load("elimination.json"), ids=lambda c: c["name"])
+def test_elimination_matches_full_system(case):
+    """qp_test.cc:101-138: EvaluateKKTConditions -> ComputeLDLT -> SolveForUpdate(0) == full-system LU, 1e-12 abs."""
+    s = orc.Solver(qp_from(case))
+    s.variables[:] = case["state"]
+    s.evaluate_kkt()
+    np.testing.assert_allclose(s.r, case["expected_r"], rtol=0, atol=1e-12)
+    assert s.compute_ldlt() == orc.ORC_OK
+    H_expected = np.array(case["expected_H"])
+    np.testing.assert_allclose(np.tril(s.H), np.tril(H_expected), rtol=0, atol=1e-13)
+    # the upper triangle and the (2,2) block stay exactly zero (qp.cc:47, :289)
+    assert np.all(np.triu(s.H, 1) == 0)
+    s.solve_for_update(0.0)
+    np.testing.assert_allclose(s.delta, case["expected_delta"], rtol=0, atol=case["tol_abs"])
+    # direct-solve variant
+    s.solve_for_update(0.0, direct=True)
+    np.testing.assert_allclose(s.delta, case["expected_delta"], rtol=0, atol=case["tol_abs"])
+    # the oracle's own BuildFullSystem + PartialPivLU (qp.cc:595-655, qp_test.cc:120-129)
+    rc, d = s.full_system_step()
+    assert rc == 0
+    np.testing.assert_allclose(d, case["expected_delta"], rtol=0, atol=case["tol_abs"])
+
+
+@pytest.mark.parametrize("case", load("elimination.json"), ids=lambda c: c["name"])
+def test_solve_no_inequalities(case):
+    """qp_test.cc:141-166"""
+    s = orc.Solver(qp_from(case))
+    s.variables[:] = case["state"]
+    s.evaluate_kkt(False)
+    assert s.compute_ldlt(False) == orc.ORC_OK
+    s.solve_no_inequalities()
+    x, _, y, _ = s.blocks(s.delta)
+    n, k = case["n"], case["k"]
+    exp = np.array(case["expected_delta_no_ineq_xy"])
+    np.testing.assert_allclose(x, exp[:n], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(y, exp[n:n + k], rtol=0, atol=1e-12)
+
+
+def test_compute_alpha_kat():
+    """qp_test.cc:244-249"""
+    g = load("alpha.json")
+    h = g["head"]
+    for c in g["cases"]:
+        assert abs(orc.compute_alpha_vec(g["x"][:h], g["dx"][:h], c["tau"]) - c["alpha"]) < g["tol_abs"]
+
+
+GUESS = {"NAIVE": orc.GUESS_NAIVE, "SOLVE_EQUALITY_CONSTRAINED": orc.GUESS_SOLVE_EQUALITY_CONSTRAINED}
+STRAT = {"COMPLEMENTARITY": orc.COMPLEMENTARITY}
+
+
+def check_kat_expectations(case, x, s, y, z, qp):
+    e = case["expect"]
+    if "x" in e:
+        np.testing.assert_allclose(x, e["x"], rtol=0, atol=e["x_tol"])
+    if "s" in e:
+        np.testing.assert_allclose(s, e["s"], rtol=0, atol=e["s_tol"])
+    for i, v in e.get("s_idx", []):
+        assert abs(s[i] - v) < e["s_tol"]
+    for i, v in e.get("z_idx", []):
+        assert abs(z[i] - v) < e["s_tol"]
+    for i, v in e.get("z_gt", []):
+        assert z[i] > v
+    if "eq_residual_tol" in e:
+        np.testing.assert_allclose(qp.A_eq @ x + qp.b_eq, 0, atol=e["eq_residual_tol"])
+    if "y_all_gt" in e:
+        assert np.all(y > e["y_all_gt"])
+
+
+@pytest.mark.parametrize("case", load("solve_kats.json"), ids=lambda c: c["name"])
+def test_full_solve_kats(case):
+    """qp_test.cc:252-471"""
+    qp = qp_from(case)
+    for guess in case["guesses"]:
+        s = orc.Solver(qp)
+        params = dict(case["params"])
+        if "barrier_strategy" in params:
+            params["barrier_strategy"] = STRAT[params["barrier_strategy"]]
+        term, its = s.solve(initial_guess_method=GUESS[guess], **params)
+        assert term == orc.SATISFIED_KKT_TOL, (case["name"], guess, term, len(its))
+        x, sl, y, z = s.blocks(s.variables)
+        check_kat_expectations(case, x, sl, y, z, qp)
+
+
+@pytest.mark.parametrize("case", load("residual.json"), ids=lambda c: c["name"])
+def test_update_hessian(case):
+    """residual_test.cc:51-182"""
+    n = case["full_size"]
+    H = np.zeros((n, n), order="F")
+    b = np.zeros(n)
+    half = orc.update_hessian(case["index"], np.array(case["J"]), case["r"], H, b)
+    np.testing.assert_allclose(H, np.array(case["expected_H_lower"]), rtol=0, atol=case["tol_abs"])
+    assert np.all(np.triu(H, 1) == 0)  # residual_test.cc:130-134
+    np.testing.assert_allclose(b, case["expected_b"], rtol=0, atol=case["tol_abs"])
+    assert abs(half - case["expected_half_sq"]) < 1e-14
+    # untouched cells stay exactly zero (residual_test.cc:143-147)
+    mask = np.zeros((n, n), bool)
+    for i in case["index"]:
+        for j in case["index"]:
+            mask[i, j] = True
+    assert np.all(H[~mask] == 0)
+
+
+def rel_inf(a, b):
+    return np.max(np.abs(a - b)) / np.max(np.abs(b))
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4"])
+@pytest.mark.parametrize("use_inverse", [True, False])
+def test_synthetic_step_vs_numpy_full_system(cfg, use_inverse):
+    """Oracle Newton step (with mu) on the synthetic fixtures == numpy full-system solve, <= 1e-11 rel-inf."""
+    z = np.load(os.path.join(GOLDEN, "synthetic.npz"))
+    g = lambda k: z[f"{cfg}_{k}"]
+    J = g("J")
+    B, m_r, n = J.shape
+    k = g("b_eq").shape[1]
+    m = g("cons_var").shape[1]
+    delta, alpha, status, _ = orc.batched_newton_step(
+        n, k, m, J=J, r=g("r"), lam=float(g("lam")), A_eq=g("A_eq"), b_eq=g("b_eq"), cons_var=g("cons_var"),
+        cons_a=g("cons_a"), cons_b=g("cons_b"), vars_=g("vars"), mu=g("mu"), use_inverse=use_inverse)
+    assert np.all(status == 0)
+    for p in range(B):
+        assert rel_inf(delta[p], g("delta")[p]) < 1e-11
+    # linearisation itself
+    G, c, _ = orc.linearize_dense(J[0], g("r")[0], float(g("lam")))
+    np.testing.assert_allclose(np.tril(G), g("G_lower")[0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(c, g("c")[0], rtol=1e-13, atol=1e-13)
+    # alpha recomputed in numpy from the state and delta (qp.cc:485-507)
+    v = g("vars")
+    for p in range(B):
+        for blk, a in ((slice(n, n + m), alpha[p, 0]), (slice(n + m + k, n + 2 * m + k), alpha[p, 1])):
+            val, d = v[p][blk], delta[p][blk]
+            cand = [-0.995 * val[i] / d[i] for i in range(m) if val[i] + d[i] <= 0 and abs(d[i]) > 0]
+            assert abs(a - min([1.0] + cand)) < 1e-12
