@@ -1,0 +1,188 @@
+/*
+ * mini_opt_hip.h -- C ABI of the MI355X-native batched interior-point Newton-step solver.
+ *
+ * This is the drop-in boundary for mini_opt's dense KKT hot path (source/qp.cc).  The reference has no FFI:
+ * its boundary is the C++ class API (include/mini_opt/qp.hpp:132-205, residual.hpp:28-117,
+ * nonlinear.hpp:33-52,127-157).  Each entry point below names the reference member function(s) it replaces;
+ * INTEGRATION.md shows the binding a mini_opt maintainer would add inside QPInteriorPointSolver /
+ * ConstrainedNonlinearLeastSquares, and mini_opt_amd/cpp/ holds the C++ facade that mirrors those classes.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no exceptions across the boundary.  Every call returns an int:
+ *    MO_OK (0) or a negative MO_ERR_* (the reference's F_ASSERT / assert::default_error cases,
+ *    assertions.hpp:68-73).  Per-problem numeric failures never abort the batch: they are written to the
+ *    caller's `status[batch]` array (MO_STATUS_*), mirroring the reference's two exceptions.
+ *  - All data pointers are DEVICE pointers on the plan's GPU (caller-owned).  The plan owns only scratch.
+ *  - A "batch" is `batch` independent QPs of identical dimensions (n, k, m, m_r).  Problem p of tensor X lives at
+ *    X + p * X_stride (strides in ELEMENTS; stride 0 = one instance shared by the whole batch).
+ *  - Matrices G (n x n, only the lower triangle is read -- qp.cc:289, :404) and A_eq (k x n) are COLUMN-MAJOR
+ *    with a leading dimension, exactly Eigen's default, so `MatrixXd::data()` can be passed unchanged.
+ *    The stacked Jacobian J (m_r x n; the reference never materialises it -- residual.hpp:198-224 accumulates
+ *    J^T J residual by residual) is ROW-MAJOR by default (each residual appends its rows); column-major is
+ *    accepted via J_layout.
+ *  - State / residual / delta vectors use the reference block order [x(n) | s(m) | y(k) | z(m)]
+ *    (qp.cc:36-42, 548-582); V = n + 2m + k.
+ *  - dtype MO_F64 is the reference's arithmetic (qp.hpp:15: double only); MO_F32 is the BASELINE.json cfg-4
+ *    extension: every floating-point tensor (incl. mu, alpha, ip records) is then float.
+ *  - Thread-safety: a plan may be used from one host thread at a time; distinct plans are independent.
+ *    Multi-GPU = one plan (and one process or thread) per device; there is no cross-device traffic.
+ */
+#ifndef MINI_OPT_HIP_H_
+#define MINI_OPT_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MO_VERSION_MAJOR 0
+#define MO_VERSION_MINOR 1
+
+/* return codes */
+#define MO_OK 0
+#define MO_ERR_INVALID_ARGUMENT (-1) /* null pointer, bad enum, bad params (CheckParams qp.cc:76-82) */
+#define MO_ERR_DIMENSION (-2)        /* dimension mismatch (Setup asserts, qp.cc:24-34) */
+#define MO_ERR_UNSUPPORTED (-3)      /* problem too large for the LDS-resident kernels, unknown dtype ... */
+#define MO_ERR_HIP (-4)              /* a HIP runtime call failed; see mo_last_error() */
+#define MO_ERR_NO_DEVICE (-5)        /* no usable gfx950 device: the HIP path never falls back to the CPU */
+
+/* per-problem status words */
+#define MO_STATUS_OK 0
+#define MO_STATUS_NONPOSITIVE_SLACK 1    /* some s <= 0 at factorisation time (F_ASSERT qp.cc:285) */
+#define MO_STATUS_FACTORIZATION_FAILED 2 /* FailedFactorization (qp.cc:303-307, qp.hpp:331-333) */
+#define MO_STATUS_NONFINITE 3            /* the computed direction contains NaN/Inf */
+#define MO_STATUS_BAD_INDEX 4            /* constraint variable index outside [0,n) (F_ASSERT qp.cc:70-72) */
+
+typedef enum { MO_F64 = 0, MO_F32 = 1 } mo_dtype;
+typedef enum { MO_COL_MAJOR = 0, MO_ROW_MAJOR = 1 } mo_layout;
+
+/* BarrierStrategy (structs.hpp:24-31), InitialGuessMethod (structs.hpp:34-41), termination (structs.hpp:97-102) */
+typedef enum { MO_COMPLEMENTARITY = 0, MO_FIXED_DECREASE = 1, MO_PREDICTOR_CORRECTOR = 2 } mo_barrier_strategy;
+typedef enum { MO_GUESS_NAIVE = 0, MO_GUESS_SOLVE_EQUALITY_CONSTRAINED = 1, MO_GUESS_USER_PROVIDED = 2 } mo_initial_guess;
+typedef enum { MO_SATISFIED_KKT_TOL = 0, MO_MAX_ITERATIONS = 1 } mo_termination;
+
+/* plan flags */
+#define MO_PLAN_FORCE_GENERIC 1u /* always use the shape-generic LDS kernel (testing / A-B measurements) */
+
+typedef struct {
+  int32_t n;   /* variables (QPInteriorPointSolver::dims_.N, qp.cc:37) */
+  int32_t k;   /* equality rows (dims_.K) */
+  int32_t m;   /* LinearInequalityConstraint entries (dims_.M); a two-sided box is two entries */
+  int32_t m_r; /* stacked residual rows for J-level input; 0 if only QP-level (G, c) input is used */
+  int32_t dtype;  /* mo_dtype */
+  int32_t device; /* HIP device ordinal */
+  uint32_t flags; /* MO_PLAN_* */
+  int32_t reserved;
+  int64_t max_batch; /* sizes plan-owned scratch (only mo_qp_solve with J-level input needs any) */
+} mo_plan_desc;
+
+typedef struct mo_plan mo_plan; /* opaque; replaces the solver-owned scratch of qp.hpp:221-231 */
+
+/* One batch of QPs (mini_opt::QP, qp.hpp:104-124) or of linearised least-squares problems
+ * (ConstrainedNonlinearLeastSquares::LinearizeAndFillQP, nonlinear.cc:170-214).
+ * Cost: give EITHER (J, r, lambda) -- then G = J^T J + lambda I (lower) and c = J^T r are formed on device
+ * (residual.hpp:206-224 summed, nonlinear.cc:187-189) -- OR (G, c).  J == NULL selects (G, c). */
+typedef struct {
+  const void* J;      int64_t J_stride; int32_t J_ld; int32_t J_layout; /* m_r x n */
+  const void* r;      int64_t r_stride;                                /* m_r */
+  double lambda;                                                      /* Levenberg-Marquardt damping, added iff > 0 */
+  const void* G;      int64_t G_stride; int32_t G_ld; int32_t reserved0; /* n x n col-major, lower read */
+  const void* c;      int64_t c_stride;                                /* n */
+  const void* A_eq;   int64_t A_stride; int32_t A_ld; int32_t reserved1; /* k x n col-major (NULL iff k == 0) */
+  const void* b_eq;   int64_t b_stride;                                /* k */
+  const int32_t* cons_var; const void* cons_a; const void* cons_b; int64_t cons_stride; /* m each: a*x[var]+b >= 0 */
+} mo_problem;
+
+/* QPInteriorPointSolver::Params (qp.hpp:134-164); mo_default_solve_params fills the reference defaults. */
+typedef struct {
+  double initial_mu;
+  double sigma;
+  double termination_kkt_tol;
+  double termination_complementarity_tol;
+  int32_t max_iterations;
+  int32_t barrier_strategy;                 /* mo_barrier_strategy */
+  int32_t decrease_mu_only_on_small_error;
+  int32_t initial_guess_method;             /* mo_initial_guess */
+  int32_t initialize_mu_with_complementarity;
+  int32_t reserved;
+} mo_solve_params;
+
+/* Records are arrays of the plan's scalar type, laid out as:
+ *   KKTError (structs.hpp:68-78)            kkt[4]  = {r_dual, r_comp, r_primal_eq, r_primal_ineq}
+ *   IPIterationOutputs (structs.hpp:53-64)  ip[6]   = {mu, alpha.primal, alpha.dual, alpha_probe.primal,
+ *                                                      alpha_probe.dual, mu_affine}   (NaN where the reference has NaN)
+ *   QPInteriorPointIteration (:81-94)       iter[14] = {kkt_initial[4], kkt_final[4], ip[6]}
+ */
+#define MO_KKT_RECORD 4
+#define MO_IP_RECORD 6
+#define MO_ITER_RECORD 14
+
+/* step flags */
+#define MO_STEP_NO_INEQUALITIES 1u    /* EvaluateKKTConditions(false) + ComputeLDLT(false) + SolveForUpdateNoInequalities
+                                         (qp.cc:366-386, used by the initial guess :455-460): only dx, dy are written,
+                                         ds = dz = 0, alpha = 1 */
+#define MO_STEP_PREDICTOR_CORRECTOR 2u /* mo_iterate only: the Mehrotra double solve of qp.cc:170-187 */
+
+const char* mo_version_string(void);
+const char* mo_status_string(int32_t status);
+/* Message of the last failing call on this host thread ("" if none). */
+const char* mo_last_error(void);
+
+void mo_default_solve_params(mo_solve_params* params);
+
+/* Replaces QPInteriorPointSolver::Setup (qp.cc:20-73): validates dimensions, selects kernels, allocates scratch. */
+int mo_plan_create(const mo_plan_desc* desc, mo_plan** plan);
+int mo_plan_destroy(mo_plan* plan);
+/* Name of the kernel variant mo_newton_step will launch for this plan and problem layout ("generic", "fused_n64", ...). */
+const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob);
+
+/* Replaces LinearizeAndFillQP's cost part (nonlinear.cc:182-189; Residual::Model::UpdateHessian, residual.hpp:186-226):
+ * G_out (n x n col-major, leading dim G_ld; lower triangle written, strict upper written as 0) = J^T J + lambda I,
+ * c_out = J^T r, half_sq_out[p] = 0.5 |r|^2 (may be NULL). */
+int mo_linearize(mo_plan* plan, const mo_problem* prob, int64_t batch, void* G_out, int64_t G_stride, int32_t G_ld,
+                 void* c_out, int64_t c_stride, void* half_sq_out, void* stream);
+
+/* Replaces EvaluateKKTConditions (qp.cc:391-420) + ComputeErrors (qp.cc:423-437):
+ * r_out [V] = [r_d | r_comp | r_pe | r_pi] (mu NOT applied, as in the reference), kkt_out [4] (may be NULL) with mu[p]. */
+int mo_kkt_residual(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* vars, int64_t vars_stride,
+                    const void* mu, int64_t mu_stride, uint32_t flags, void* r_out, int64_t r_stride, void* kkt_out,
+                    void* stream);
+
+/* THE HOT PATH.  One dense KKT Newton step per problem on the caller's state; replaces the sequence
+ *   EvaluateKKTConditions (qp.cc:391-420) -> ComputeLDLT (qp.cc:275-316) -> SolveForUpdate(mu) (qp.cc:318-364)
+ *   -> ComputeAlpha(tau) (qp.cc:485-507)
+ * (what qp_test.cc:132-134 calls through `friend`), including the J^T J assembly when J-level input is given.
+ * The direction is obtained by a direct LDL^T solve; the reference's explicit inverse (qp.cc:310-311) is not formed.
+ *   vars  [batch][V]  in   strictly interior state (s > 0)
+ *   mu    per-problem barrier parameter (mu_stride 0: one shared value); ignored (0) if m == 0 (qp.cc:165-167)
+ *   delta [batch][V]  out  [dx | ds | dy | dz]   (NaN-filled for problems whose status != 0)
+ *   alpha [batch][2]  out  {primal, dual} step lengths (may be NULL)
+ *   status[batch]     out  MO_STATUS_* (may be NULL) */
+int mo_newton_step(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* vars, int64_t vars_stride,
+                   const void* mu, int64_t mu_stride, double tau, uint32_t flags, void* delta, int64_t delta_stride,
+                   void* alpha, int32_t* status, void* stream);
+
+/* Replaces QPInteriorPointSolver::Iterate (qp.cc:153-201): Newton step (optionally predictor-corrector,
+ * qp.cc:170-187 with ComputePredictorCorrectorMuAffine :519-537), ComputeAlpha(0.995), and the state update
+ * x,s += alpha_p (dx,ds); y,z += alpha_d (dy,dz) IN PLACE in vars.  ip_out [batch][6] (may be NULL),
+ * delta (may be NULL). */
+int mo_iterate(mo_plan* plan, const mo_problem* prob, int64_t batch, void* vars, int64_t vars_stride, const void* mu,
+               int64_t mu_stride, int32_t barrier_strategy, void* delta, int64_t delta_stride, void* ip_out,
+               int32_t* status, void* stream);
+
+/* Replaces QPInteriorPointSolver::Solve (qp.cc:100-151) incl. ComputeInitialGuess (qp.cc:439-482): the whole
+ * interior-point loop runs on device, one problem per workgroup, with per-problem early termination.
+ *   vars            [batch][V] in/out (input only read for MO_GUESS_USER_PROVIDED)
+ *   termination     [batch] out mo_termination
+ *   num_iterations  [batch] out
+ *   iterations      [batch][max_iterations][14] out (may be NULL)
+ *   lagrange        [batch][2] out {min(y), |y|_inf} (may be NULL; qp.cc:539-546) */
+int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_solve_params* params, void* vars,
+                int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
+                int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINI_OPT_HIP_H_ */

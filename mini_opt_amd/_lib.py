@@ -1,0 +1,108 @@
+"""Loader + ctypes declarations for the C ABI in include/mini_opt_hip.h (lib/libminiopt_hip.so).
+
+The HIP library is the product: if it is missing, this module raises -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libminiopt_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MO_OK = 0
+MO_F64, MO_F32 = 0, 1
+MO_COL_MAJOR, MO_ROW_MAJOR = 0, 1
+MO_PLAN_FORCE_GENERIC = 1
+MO_STEP_NO_INEQUALITIES = 1
+MO_STATUS_OK, MO_STATUS_NONPOSITIVE_SLACK, MO_STATUS_FACTORIZATION_FAILED, MO_STATUS_NONFINITE, MO_STATUS_BAD_INDEX = range(5)
+MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
+
+# every symbol include/mini_opt_hip.h declares
+EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
+           "mo_plan_destroy", "mo_plan_step_kernel", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
+           "mo_qp_solve"]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("m", C.c_int32), ("m_r", C.c_int32), ("dtype", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_int32), ("max_batch", C.c_int64)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("J", C.c_void_p), ("J_stride", C.c_int64), ("J_ld", C.c_int32), ("J_layout", C.c_int32),
+                ("r", C.c_void_p), ("r_stride", C.c_int64),
+                ("lam", C.c_double),
+                ("G", C.c_void_p), ("G_stride", C.c_int64), ("G_ld", C.c_int32), ("reserved0", C.c_int32),
+                ("c", C.c_void_p), ("c_stride", C.c_int64),
+                ("A_eq", C.c_void_p), ("A_stride", C.c_int64), ("A_ld", C.c_int32), ("reserved1", C.c_int32),
+                ("b_eq", C.c_void_p), ("b_stride", C.c_int64),
+                ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64)]
+
+
+class SolveParams(C.Structure):
+    _fields_ = [("initial_mu", C.c_double), ("sigma", C.c_double), ("termination_kkt_tol", C.c_double),
+                ("termination_complementarity_tol", C.c_double), ("max_iterations", C.c_int32),
+                ("barrier_strategy", C.c_int32), ("decrease_mu_only_on_small_error", C.c_int32),
+                ("initial_guess_method", C.c_int32), ("initialize_mu_with_complementarity", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "mini_opt_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libminiopt_hip.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "mini_opt_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, u32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_double
+    L.mo_version_string.restype = C.c_char_p
+    L.mo_status_string.restype = C.c_char_p
+    L.mo_status_string.argtypes = [i32]
+    L.mo_last_error.restype = C.c_char_p
+    L.mo_default_solve_params.argtypes = [C.POINTER(SolveParams)]
+    L.mo_default_solve_params.restype = None
+    L.mo_plan_create.argtypes = [C.POINTER(PlanDesc), C.POINTER(vp)]
+    L.mo_plan_destroy.argtypes = [vp]
+    L.mo_plan_step_kernel.argtypes = [vp, C.POINTER(Problem)]
+    L.mo_plan_step_kernel.restype = C.c_char_p
+    L.mo_linearize.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, i32, vp, i64, vp, vp]
+    L.mo_kkt_residual.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, u32, vp, i64, vp, vp]
+    L.mo_newton_step.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, dbl, u32, vp, i64, vp, vp, vp]
+    L.mo_iterate.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp]
+    L.mo_qp_solve.argtypes = [vp, C.POINTER(Problem), i64, C.POINTER(SolveParams), vp, i64, vp, vp, vp, vp, vp, vp]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError if the library does not export what the header declares
+    _lib = L
+    return L
+
+
+class MiniOptError(RuntimeError):
+    """Argument / dimension errors of the C ABI (the reference throws assert::default_error, assertions.hpp:49-59)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mini_opt_hip error {code}: {msg}")
+        self.code = code
+
+
+def check(rc: int) -> None:
+    if rc != MO_OK:
+        raise MiniOptError(rc, lib().mo_last_error().decode())

@@ -1,0 +1,715 @@
+// kkt_generic.hip -- shape-generic LDS-resident KKT kernel for gfx950 (one problem per 256-thread workgroup).
+//
+// Handles any (n, k, m, m_r) whose reduced KKT matrix fits the CU's 160 KiB LDS, in f64 or f32, and every
+// mode of the C ABI (linearise / residual / Newton step / Iterate / full Solve).  The fixed-shape fused kernels
+// (kkt_fused.hip) are the fast path for BASELINE.json's configs; this kernel is the general path and the
+// on-device reference they are A/B-tested against.
+//
+// Reference arithmetic reproduced (citations into /root/reference):
+//   J^T J / J^T r / lambda      residual.hpp:206-224, nonlinear.cc:182-189
+//   KKT residual                qp.cc:391-420           errors qp.cc:423-437
+//   reduced-KKT assembly        qp.cc:281-298
+//   LDL^T                       qp.cc:302 (Eigen LDLT<MatrixXd,Lower>): here a right-looking LDL^T in natural order.
+//                               Eigen's "pivoting" only orders by the ORIGINAL |H_ii| (its update is left-looking), which
+//                               changes rounding, not the solution; zero-pivot rules are kept (zero pivot tolerated iff
+//                               the column below is zero, failure if a non-zero pivot follows).
+//   solve + back-substitution   qp.cc:337-363 by a direct solve (the explicit inverse of qp.cc:310-311 is not formed)
+//   alpha / mu / mu_affine      qp.cc:485-537       Iterate qp.cc:153-201       Solve qp.cc:100-151, 439-482
+//
+// LDS layout: H is column-major with an ODD leading dimension (conflict-free column AND row access with ds_read_b64),
+// followed by the state, residual, direction, rhs and constraint vectors and a small row-chunk of J.
+#include <math.h>
+
+#include "mo_kernels.h"
+
+namespace mo {
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename T> struct Ws {
+  T* H; int ldh;
+  T* vars; T* res; T* delta; T* daff;  // V each
+  T* cvec;                             // n
+  T* beq;                              // k
+  T* rhs; T* invd;                     // P each
+  T* ca; T* cb;                        // m each
+  T* Jc; T* rc; int chunk_rows;        // J row chunk
+  T* red;                              // 16 scalars
+  int* cv;                             // m
+  int* iflag;                          // 8
+};
+
+__host__ __device__ inline int odd_ld(int P) { return P | 1; }
+
+__host__ __device__ inline int chunk_rows_for(int n, int m_r, int elem) {
+  if (m_r <= 0) return 0;
+  int cr = 8192 / (n * elem);
+  if (cr < 4) cr = 4;
+  if (cr > m_r) cr = m_r;
+  return cr;
+}
+
+template <typename T>
+__host__ __device__ inline size_t ws_elems(int n, int k, int m, int m_r) {
+  const int P = n + k, V = n + 2 * m + k;
+  const int cr = chunk_rows_for(n, m_r, (int)sizeof(T));
+  size_t e = (size_t)P * odd_ld(P) + 4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + (size_t)cr * n + cr + 16;
+  return e;
+}
+
+template <typename T>
+__device__ inline void carve(Ws<T>& w, char* smem, int n, int k, int m, int m_r) {
+  const int P = n + k, V = n + 2 * m + k;
+  T* p = reinterpret_cast<T*>(smem);
+  w.ldh = odd_ld(P);
+  w.H = p; p += (size_t)P * w.ldh;
+  w.vars = p; p += V; w.res = p; p += V; w.delta = p; p += V; w.daff = p; p += V;
+  w.cvec = p; p += n; w.beq = p; p += k;
+  w.rhs = p; p += P; w.invd = p; p += P;
+  w.ca = p; p += m; w.cb = p; p += m;
+  w.chunk_rows = chunk_rows_for(n, m_r, (int)sizeof(T));
+  w.Jc = p; p += (size_t)w.chunk_rows * n; w.rc = p; p += w.chunk_rows;
+  w.red = p; p += 16;
+  w.cv = reinterpret_cast<int*>(p);
+  w.iflag = w.cv + m;
+}
+
+// ---- small helpers -------------------------------------------------------------------------------------------
+__device__ inline double rl(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline float rl(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ inline double absT(double v) { return fabs(v); }
+__device__ inline float absT(float v) { return fabsf(v); }
+__device__ inline double sqrtT(double v) { return sqrt(v); }
+__device__ inline float sqrtT(float v) { return sqrtf(v); }
+template <typename T> __device__ inline T nanT() { return (T)__builtin_nan(""); }
+template <typename T> __device__ inline bool finiteT(T v) { return __builtin_isfinite(v); }
+
+template <typename T> __device__ inline T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T> __device__ inline T wave_min(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o, 64); v = u < v ? u : v; }
+  return v;
+}
+
+// ---- phases --------------------------------------------------------------------------------------------------
+
+// H <- 0 ; H.lower(n x n) <- G.lower ; H[n.., 0..n) <- A_eq ; cvec <- c ; beq <- b_eq      (qp.cc:47, 289-292)
+template <typename T>
+__device__ void load_qp(const Ws<T>& w, int n, int k, const T* G, int G_ld, const T* c, const T* A, int A_ld,
+                        const T* b, int tid) {
+  const int P = n + k;
+  for (int idx = tid; idx < P * w.ldh; idx += kThreads) w.H[idx] = (T)0;
+  __syncthreads();
+  if (G) {
+    for (int j = 0; j < n; ++j)
+      for (int i = j + tid; i < n; i += kThreads) w.H[i + (size_t)j * w.ldh] = G[i + (size_t)j * G_ld];
+    for (int i = tid; i < n; i += kThreads) w.cvec[i] = c[i];
+  }
+  for (int j = 0; j < n; ++j)
+    for (int q = tid; q < k; q += kThreads) w.H[n + q + (size_t)j * w.ldh] = A[q + (size_t)j * A_ld];
+  for (int q = tid; q < k; q += kThreads) w.beq[q] = b[q];
+  __syncthreads();
+}
+
+// H.lower(n x n) += J^T J, cvec = J^T r, diag += lambda; returns 0.5|r|^2 in w.red[8]   (residual.hpp:206-225,
+// nonlinear.cc:182-189).  H must be zero in its n x n block and cvec is overwritten.
+template <typename T>
+__device__ void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r,
+                               T lambda, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n; i += kThreads) w.cvec[i] = (T)0;
+  if (tid == 0) w.red[8] = (T)0;
+  __syncthreads();
+  const int CR = w.chunk_rows;
+  for (int q0 = 0; q0 < m_r; q0 += CR) {
+    const int rows = (m_r - q0 < CR) ? (m_r - q0) : CR;
+    if (row_major) {
+      for (int idx = tid; idx < rows * n; idx += kThreads) {
+        const int q = idx / n, i = idx - q * n;
+        w.Jc[idx] = J[(size_t)(q0 + q) * J_ld + i];
+      }
+    } else {
+      for (int idx = tid; idx < rows * n; idx += kThreads) {
+        const int i = idx / rows, q = idx - i * rows;
+        w.Jc[q * n + i] = J[(size_t)i * J_ld + q0 + q];
+      }
+    }
+    for (int idx = tid; idx < rows; idx += kThreads) w.rc[idx] = r[q0 + idx];
+    __syncthreads();
+    // each wave owns groups of 4 columns; lanes own rows i >= j0
+    for (int j0 = wave * 4; j0 < n; j0 += 16) {
+      const int jc0 = j0, jc1 = (j0 + 1 < n) ? j0 + 1 : n - 1, jc2 = (j0 + 2 < n) ? j0 + 2 : n - 1,
+                jc3 = (j0 + 3 < n) ? j0 + 3 : n - 1;
+      for (int i0 = j0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const int ic = i < n ? i : n - 1;
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int q = 0; q < rows; ++q) {
+          const T* row = w.Jc + (size_t)q * n;
+          const T ji = row[ic];
+          a0 += ji * row[jc0]; a1 += ji * row[jc1]; a2 += ji * row[jc2]; a3 += ji * row[jc3];
+        }
+        if (i < n) {
+          if (i >= j0) w.H[i + (size_t)j0 * w.ldh] += a0;
+          if (j0 + 1 < n && i >= j0 + 1) w.H[i + (size_t)(j0 + 1) * w.ldh] += a1;
+          if (j0 + 2 < n && i >= j0 + 2) w.H[i + (size_t)(j0 + 2) * w.ldh] += a2;
+          if (j0 + 3 < n && i >= j0 + 3) w.H[i + (size_t)(j0 + 3) * w.ldh] += a3;
+        }
+      }
+    }
+    for (int i = tid; i < n; i += kThreads) {
+      T acc = 0;
+      for (int q = 0; q < rows; ++q) acc += w.Jc[(size_t)q * n + i] * w.rc[q];
+      w.cvec[i] += acc;
+    }
+    if (tid == 0) {
+      T acc = 0;
+      for (int q = 0; q < rows; ++q) acc += w.rc[q] * w.rc[q];
+      w.red[8] += acc;
+    }
+    __syncthreads();
+  }
+  if (lambda > (T)0)
+    for (int i = tid; i < n; i += kThreads) w.H[i + (size_t)i * w.ldh] += lambda;
+  if (tid == 0) w.red[8] *= (T)0.5;
+  __syncthreads();
+}
+
+// EvaluateKKTConditions, qp.cc:391-420.  H must hold G (lower) and A_eq (no Sigma yet).
+template <typename T>
+__device__ void eval_kkt(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+  const T* x = w.vars; const T* s = w.vars + n; const T* y = w.vars + n + m; const T* z = w.vars + n + m + k;
+  T* r_d = w.res; T* r_comp = w.res + n; T* r_pe = w.res + n + m; T* r_pi = w.res + n + m + k;
+  for (int i = tid; i < n; i += kThreads) {
+    T acc = 0;
+    for (int j = 0; j <= i; ++j) acc += w.H[i + (size_t)j * w.ldh] * x[j];       // selfadjointView<Lower>, :404
+    for (int j = i + 1; j < n; ++j) acc += w.H[j + (size_t)i * w.ldh] * x[j];
+    T rd = acc + w.cvec[i];
+    if (k > 0) {
+      T acc2 = 0;
+      for (int q = 0; q < k; ++q) acc2 += w.H[n + q + (size_t)i * w.ldh] * y[q];  // :406
+      rd -= acc2;
+    }
+    if (include_ineq) {
+      for (int c = 0; c < m; ++c)                                                 // :413-415, reference order per variable
+        if (w.cv[c] == i) rd -= w.ca[c] * z[c];
+    }
+    r_d[i] = rd;
+  }
+  for (int q = tid; q < k; q += kThreads) {                                       // :408
+    T acc = 0;
+    for (int j = 0; j < n; ++j) acc += w.H[n + q + (size_t)j * w.ldh] * x[j];
+    r_pe[q] = acc + w.beq[q];
+  }
+  if (include_ineq) {
+    for (int c = tid; c < m; c += kThreads) {                                     // :416-417
+      r_pi[c] = w.ca[c] * x[w.cv[c]] + w.cb[c] - s[c];
+      r_comp[c] = s[c] * z[c];
+    }
+  }
+  __syncthreads();
+}
+
+// ComputeErrors, qp.cc:423-437 -> w.red[0..3]
+template <typename T>
+__device__ void compute_errors(const Ws<T>& w, int n, int k, int m, T mu, int tid) {
+  if (tid < 64) {
+    const T* r_d = w.res; const T* r_comp = w.res + n; const T* r_pe = w.res + n + m; const T* r_pi = w.res + n + m + k;
+    T a = 0, b = 0, c1 = 0, c2 = 0, d = 0;
+    for (int i = tid; i < n; i += 64) a += r_d[i] * r_d[i];
+    for (int i = tid; i < k; i += 64) b += r_pe[i] * r_pe[i];
+    for (int i = tid; i < m; i += 64) { c1 += r_comp[i] * r_comp[i]; c2 += r_comp[i]; d += r_pi[i] * r_pi[i]; }
+    a = wave_sum(a); b = wave_sum(b); c1 = wave_sum(c1); c2 = wave_sum(c2); d = wave_sum(d);
+    if (tid == 0) {
+      w.red[0] = sqrtT(a);
+      w.red[2] = k > 0 ? sqrtT(b) : (T)0;
+      if (m > 0) {
+        const T corrected = c1 - 2 * (c2 * mu) + (mu * mu) * (T)m;                // :432
+        w.red[1] = sqrtT(corrected > (T)0 ? corrected : (T)0);
+        w.red[3] = sqrtT(d);
+      } else {
+        w.red[1] = 0; w.red[3] = 0;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ComputeMu, qp.cc:509-516 -> w.red[4]
+template <typename T>
+__device__ void compute_mu(const Ws<T>& w, int n, int k, int m, int tid) {
+  if (tid < 64) {
+    const T* s = w.vars + n; const T* z = w.vars + n + m + k;
+    T a = 0;
+    for (int i = tid; i < m; i += 64) a += s[i] * z[i];
+    a = wave_sum(a);
+    if (tid == 0) w.red[4] = m > 0 ? a / (T)m : (T)0;
+  }
+  __syncthreads();
+}
+
+// Reduced-KKT assembly (Sigma on the diagonal, qp.cc:293-298) + LDL^T.  Returns MO_STATUS_*.
+template <typename T>
+__device__ int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+  const int P = n + k;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (include_ineq) {
+    const T* s = w.vars + n; const T* z = w.vars + n + m + k;
+    for (int c = tid; c < m; c += kThreads)
+      if (!(s[c] > (T)0)) w.iflag[0] = 1;                                        // F_ASSERT qp.cc:285
+    __syncthreads();
+    if (w.iflag[0]) return MO_STATUS_NONPOSITIVE_SLACK;
+    for (int v = tid; v < n; v += kThreads) {
+      T hv = w.H[v + (size_t)v * w.ldh];
+      for (int c = 0; c < m; ++c)
+        if (w.cv[c] == v) hv += w.ca[c] * (z[c] / s[c]) * w.ca[c];               // :296, accumulates in constraint order
+      w.H[v + (size_t)v * w.ldh] = hv;
+    }
+    __syncthreads();
+  }
+  bool found_zero = false;
+  for (int kk = 0; kk < P; ++kk) {
+    const T* colk = w.H + (size_t)kk * w.ldh;
+    const T d = colk[kk];
+    const bool valid = absT(d) > (T)0;
+    if (!valid) {  // zero (or NaN) pivot: tolerated iff the column below is exactly zero (Eigen LDLT semantics)
+      bool nz = false;
+      for (int i = kk + 1 + tid; i < P; i += kThreads) nz |= !(colk[i] == (T)0);
+      if (nz || !(d == (T)0)) w.iflag[1] = 1;
+      if (tid == 0) w.invd[kk] = (T)0;
+      __syncthreads();
+      if (w.iflag[1]) return MO_STATUS_FACTORIZATION_FAILED;
+      found_zero = true;
+      continue;
+    }
+    if (found_zero) return MO_STATUS_FACTORIZATION_FAILED;  // non-zero pivot after a zero pivot
+    const T inv = (T)1 / d;
+    if (tid == 0) w.invd[kk] = inv;
+    for (int j = kk + 1 + wave; j < P; j += 4) {
+      const T wj = colk[j] * inv;
+      T* colj = w.H + (size_t)j * w.ldh;
+      for (int i = j + lane; i < P; i += 64) colj[i] -= colk[i] * wj;
+    }
+    __syncthreads();
+  }
+  return MO_STATUS_OK;
+}
+
+// Solve (L D L^T) sol = rhs in place, wave 0 only; H holds W = L D below the diagonal, invd = 1/D.
+template <typename T>
+__device__ void wave_solve(const Ws<T>& w, int P, int lane) {
+  const int r0 = lane, r1 = lane + 64, r2 = lane + 128;
+  T b0 = r0 < P ? w.rhs[r0] : (T)0, b1 = r1 < P ? w.rhs[r1] : (T)0, b2 = r2 < P ? w.rhs[r2] : (T)0;
+  for (int kk = 0; kk < P; ++kk) {  // forward: t = L^-1 b
+    const T src = kk < 64 ? b0 : (kk < 128 ? b1 : b2);
+    const T tk = rl(src, kk & 63) * w.invd[kk];
+    const T* col = w.H + (size_t)kk * w.ldh;
+    if (r0 > kk && r0 < P) b0 -= col[r0] * tk;
+    if (r1 > kk && r1 < P) b1 -= col[r1] * tk;
+    if (r2 > kk && r2 < P) b2 -= col[r2] * tk;
+  }
+  for (int kk = P - 1; kk >= 0; --kk) {  // backward: x_k = invd_k (t_k - sum_{i>k} w_ik x_i), column oriented
+    const T src = kk < 64 ? b0 : (kk < 128 ? b1 : b2);
+    const T xk = rl(src, kk & 63) * w.invd[kk];
+    const T* row = w.H + kk;
+    if (r0 < kk) b0 -= row[(size_t)r0 * w.ldh] * xk;
+    if (r1 < kk) b1 -= row[(size_t)r1 * w.ldh] * xk;
+    if (r2 < kk) b2 -= row[(size_t)r2 * w.ldh] * xk;
+  }
+  if (r0 < P) w.rhs[r0] = b0 * w.invd[r0];
+  if (r1 < P) w.rhs[r1] = b1 * w.invd[r1];
+  if (r2 < P) w.rhs[r2] = b2 * w.invd[r2];
+}
+
+// SolveForUpdate (qp.cc:318-364) / SolveForUpdateNoInequalities (qp.cc:366-386) with the factorisation in H.
+template <typename T>
+__device__ void solve_for_update(const Ws<T>& w, int n, int k, int m, T mu, bool include_ineq, int tid) {
+  const int P = n + k;
+  const T* s = w.vars + n; const T* z = w.vars + n + m + k;
+  const T* r_d = w.res; const T* r_comp = w.res + n; const T* r_pe = w.res + n + m; const T* r_pi = w.res + n + m + k;
+  const T* ds_aff = w.daff + n; const T* dz_aff = w.daff + n + m + k;
+  for (int v = tid; v < n; v += kThreads) {
+    T ra = r_d[v];                                                                // :337
+    if (include_ineq) {
+      for (int c = 0; c < m; ++c) {
+        if (w.cv[c] == v) {                                                       // :340-341
+          ra += w.ca[c] * (z[c] / s[c]) * r_pi[c];
+          ra += w.ca[c] * (r_comp[c] + (ds_aff[c] * dz_aff[c]) - mu) / s[c];
+        }
+      }
+    }
+    w.rhs[v] = -ra;
+  }
+  for (int q = tid; q < k; q += kThreads) w.rhs[n + q] = -r_pe[q];
+  __syncthreads();
+  if (tid < 64) wave_solve(w, P, tid);
+  __syncthreads();
+  T* dx = w.delta; T* ds = w.delta + n; T* dy = w.delta + n + m; T* dz = w.delta + n + m + k;
+  for (int i = tid; i < n; i += kThreads) dx[i] = w.rhs[i];
+  for (int q = tid; q < k; q += kThreads) dy[q] = -w.rhs[n + q];                   // py is negated, :353
+  __syncthreads();
+  for (int c = tid; c < m; c += kThreads) {
+    if (include_ineq) {                                                           // :359-363
+      const T dsv = w.ca[c] * dx[w.cv[c]] + r_pi[c];
+      ds[c] = dsv;
+      dz[c] = -(z[c] / s[c]) * dsv - ((T)1 / s[c]) * (r_comp[c] + (ds_aff[c] * dz_aff[c]) - mu);
+    } else {
+      ds[c] = (T)0; dz[c] = (T)0;
+    }
+  }
+  __syncthreads();
+}
+
+// ComputeAlpha, qp.cc:485-507 -> w.red[5] (primal), w.red[6] (dual)
+template <typename T>
+__device__ void compute_alpha(const Ws<T>& w, int n, int k, int m, T tau, int tid) {
+  if (tid < 64) {
+    const T* s = w.vars + n; const T* z = w.vars + n + m + k;
+    const T* ds = w.delta + n; const T* dz = w.delta + n + m + k;
+    T ap = 1, ad = 1;
+    for (int i = tid; i < m; i += 64) {
+      if (s[i] + ds[i] <= (T)0 && absT(ds[i]) > (T)0) { const T cnd = -tau * s[i] / ds[i]; ap = cnd < ap ? cnd : ap; }
+      if (z[i] + dz[i] <= (T)0 && absT(dz[i]) > (T)0) { const T cnd = -tau * z[i] / dz[i]; ad = cnd < ad ? cnd : ad; }
+    }
+    ap = wave_min(ap); ad = wave_min(ad);
+    if (tid == 0) { w.red[5] = ap; w.red[6] = ad; }
+  }
+  __syncthreads();
+}
+
+// ComputePredictorCorrectorMuAffine, qp.cc:519-537 -> w.red[7]
+template <typename T>
+__device__ void compute_mu_affine(const Ws<T>& w, int n, int k, int m, T mu, T ap, T ad, int tid) {
+  if (tid < 64) {
+    const T* s = w.vars + n; const T* z = w.vars + n + m + k;
+    const T* ds = w.daff + n; const T* dz = w.daff + n + m + k;
+    T a = 0, b = 0, c = 0;
+    for (int i = tid; i < m; i += 64) { a += s[i] * dz[i]; b += z[i] * ds[i]; c += ds[i] * dz[i]; }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if (tid == 0) {
+      T ma = mu;
+      ma += ad * a / (T)m;
+      ma += ap * b / (T)m;
+      ma += (ad * ap) * c / (T)m;
+      w.red[7] = ma > (T)0 ? ma : (T)0;
+    }
+  }
+  __syncthreads();
+}
+
+// Iterate's solve part (qp.cc:163-193), state update excluded.  Residual must be current, H = G + A.
+// ip[6] receives IPIterationOutputs.  Returns MO_STATUS_*.
+template <typename T>
+__device__ int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input, int strategy, T tau, T* ip, int tid) {
+  const int V = n + 2 * m + k;
+  ip[0] = mu_input; ip[1] = 1; ip[2] = 1; ip[3] = nanT<T>(); ip[4] = nanT<T>(); ip[5] = nanT<T>();
+  for (int i = tid; i < V; i += kThreads) w.daff[i] = (T)0;                        // delta_affine_.setZero(), :315
+  const int st = assemble_and_factor(w, n, k, m, true, tid);
+  if (st != MO_STATUS_OK) return st;
+  if (m == 0) {
+    solve_for_update(w, n, k, m, (T)0, true, tid);                                // :165-167
+  } else if (strategy != MO_PREDICTOR_CORRECTOR) {
+    solve_for_update(w, n, k, m, mu_input, true, tid);                            // :169
+  } else {
+    solve_for_update(w, n, k, m, (T)0, true, tid);                                // :173
+    compute_alpha(w, n, k, m, (T)1, tid);                                         // :174
+    ip[3] = w.red[5]; ip[4] = w.red[6];
+    for (int i = tid; i < V; i += kThreads) w.daff[i] = w.delta[i];               // :177
+    __syncthreads();
+    compute_mu_affine(w, n, k, m, mu_input, ip[3], ip[4], tid);                   // :180
+    ip[5] = w.red[7];
+    const T ratio = ip[5] / mu_input;
+    const T sigma = ratio * ratio * ratio;                                        // :182
+    ip[0] = sigma * mu_input;                                                     // :183
+    solve_for_update(w, n, k, m, ip[0], true, tid);                               // :187
+  }
+  if (m > 0) {                                                                    // :191-193
+    compute_alpha(w, n, k, m, tau, tid);
+    ip[1] = w.red[5]; ip[2] = w.red[6];
+  }
+  return MO_STATUS_OK;
+}
+
+// x,s += alpha_p (dx,ds); y,z += alpha_d (dy,dz), qp.cc:196-199
+template <typename T>
+__device__ void update_state(const Ws<T>& w, int n, int k, int m, T ap, T ad, int tid) {
+  const int V = n + 2 * m + k;
+  for (int i = tid; i < V; i += kThreads) {
+    const bool primal = i < n + m;
+    w.vars[i] += w.delta[i] * (primal ? ap : ad);
+  }
+  __syncthreads();
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ws<T> w;
+  const int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
+  const int V = n + 2 * m + k;
+  carve(w, smem, n, k, m, m_r);
+  const int tid = threadIdx.x;
+  const bool j_level = a.J != nullptr;
+
+  for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
+    __syncthreads();  // previous problem's readers are done with LDS
+    const T* Jp = j_level ? (const T*)a.J + p * a.J_stride : nullptr;
+    const T* rp = j_level ? (const T*)a.r + p * a.r_stride : nullptr;
+    const T* Gp = a.G ? (const T*)a.G + p * a.G_stride : nullptr;
+    const T* cp = a.c ? (const T*)a.c + p * a.c_stride : nullptr;
+    const T* Ap = k > 0 ? (const T*)a.A + p * a.A_stride : nullptr;
+    const T* bp = k > 0 ? (const T*)a.b + p * a.b_stride : nullptr;
+    int G_ld = a.G_ld;
+
+    // constraints + state into LDS
+    if (tid < 8) w.iflag[tid] = 0;
+    __syncthreads();
+    if (m > 0 && MODE != MODE_LINEARIZE) {
+      const int* cvp = a.cons_var + p * a.cons_stride;
+      const T* cap = (const T*)a.cons_a + p * a.cons_stride;
+      const T* cbp = (const T*)a.cons_b + p * a.cons_stride;
+      for (int c = tid; c < m; c += kThreads) {
+        const int v = cvp[c];
+        if (v < 0 || v >= n) { w.iflag[2] = 1; w.cv[c] = 0; } else { w.cv[c] = v; }
+        w.ca[c] = cap[c]; w.cb[c] = cbp[c];
+      }
+    }
+    if (a.vars && MODE != MODE_LINEARIZE) {
+      const T* vp = (const T*)a.vars + p * a.vars_stride;
+      for (int i = tid; i < V; i += kThreads) w.vars[i] = vp[i];
+    }
+    T mu_p = (T)0;
+    if (a.mu) mu_p = ((const T*)a.mu)[p * a.mu_stride];
+
+    // cost: QP-level (G, c) or J-level (J, r, lambda)
+    load_qp(w, n, k, j_level ? (const T*)nullptr : Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
+    if (j_level) {
+      accumulate_jtj(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, (T)a.lambda, tid);
+      if (MODE == MODE_LINEARIZE || MODE == MODE_SOLVE) {
+        // LINEARIZE output, or the per-problem G scratch the Solve loop reloads after each factorisation
+        T* Go = (T*)a.G_out + p * a.G_out_stride;
+        for (int j = 0; j < n; ++j)
+          for (int i = tid; i < n; i += kThreads) Go[i + (size_t)j * a.G_out_ld] = i >= j ? w.H[i + (size_t)j * w.ldh] : (T)0;
+        T* co = (T*)a.c_out + p * a.c_out_stride;
+        for (int i = tid; i < n; i += kThreads) co[i] = w.cvec[i];
+        if (a.half_sq_out && tid == 0) ((T*)a.half_sq_out)[p] = w.red[8];
+        Gp = Go; cp = co; G_ld = a.G_out_ld;
+        __threadfence();  // the Solve loop re-reads this scratch from other threads of the workgroup
+        __syncthreads();
+      }
+    }
+    if (MODE == MODE_LINEARIZE) continue;
+
+    int st = w.iflag[2] ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;  // uniform: iflag written before the barriers above
+
+    if (MODE == MODE_RESIDUAL) {
+      const bool inc = !(a.flags & MO_STEP_NO_INEQUALITIES);
+      eval_kkt(w, n, k, m, inc, tid);
+      compute_errors(w, n, k, m, mu_p, tid);
+      T* ro = (T*)a.r_out + p * a.r_out_stride;
+      for (int i = tid; i < V; i += kThreads) ro[i] = w.res[i];
+      if (a.kkt_out && tid < 4) ((T*)a.kkt_out)[p * 4 + tid] = w.red[tid];  // LDS, runtime index is fine
+      if (a.status && tid == 0) a.status[p] = st;
+      continue;
+    }
+
+    if (MODE == MODE_STEP || MODE == MODE_ITERATE) {
+      T ip[6];
+      const bool no_ineq = (a.flags & MO_STEP_NO_INEQUALITIES) != 0;
+      for (int i = tid; i < V; i += kThreads) { w.delta[i] = (T)0; w.daff[i] = (T)0; }
+      if (st == MO_STATUS_OK) {
+        eval_kkt(w, n, k, m, !no_ineq, tid);
+        if (no_ineq) {
+          st = assemble_and_factor(w, n, k, m, false, tid);
+          if (st == MO_STATUS_OK) solve_for_update(w, n, k, m, (T)0, false, tid);
+          ip[0] = mu_p; ip[1] = 1; ip[2] = 1; ip[3] = ip[4] = ip[5] = nanT<T>();
+        } else {
+          const int strat = (MODE == MODE_ITERATE) ? a.barrier_strategy : MO_COMPLEMENTARITY;
+          st = newton_direction(w, n, k, m, mu_p, strat, (T)a.tau, ip, tid);
+        }
+      }
+      if (st == MO_STATUS_OK) {  // non-finite direction?
+        bool bad = false;
+        for (int i = tid; i < V; i += kThreads) bad |= !finiteT(w.delta[i]);
+        if (bad) w.iflag[3] = 1;
+        __syncthreads();
+        if (w.iflag[3]) st = MO_STATUS_NONFINITE;
+      }
+      if (MODE == MODE_ITERATE && st == MO_STATUS_OK) {
+        update_state(w, n, k, m, ip[1], ip[2], tid);
+        T* vp = (T*)a.vars + p * a.vars_stride;
+        for (int i = tid; i < V; i += kThreads) vp[i] = w.vars[i];
+      }
+      if (a.delta) {
+        T* dp = (T*)a.delta + p * a.delta_stride;
+        for (int i = tid; i < V; i += kThreads) dp[i] = st == MO_STATUS_OK ? w.delta[i] : nanT<T>();
+      }
+      if (tid == 0) {  // constant indices only: a runtime-indexed register array would live in scratch
+        if (a.alpha) {
+          ((T*)a.alpha)[p * 2] = st == MO_STATUS_OK ? ip[1] : nanT<T>();
+          ((T*)a.alpha)[p * 2 + 1] = st == MO_STATUS_OK ? ip[2] : nanT<T>();
+        }
+        if (a.ip_out) {
+#pragma unroll
+          for (int i = 0; i < MO_IP_RECORD; ++i) ((T*)a.ip_out)[p * MO_IP_RECORD + i] = ip[i];
+        }
+      }
+      if (a.status && tid == 0) a.status[p] = st;
+      continue;
+    }
+
+    // ---- MODE_SOLVE: QPInteriorPointSolver::Solve, qp.cc:100-151 ------------------------------------------------
+    {
+      const mo_solve_params& sp = a.sp;
+      T* x = w.vars; T* s = w.vars + n; T* y = w.vars + n + m; T* z = w.vars + n + m + k;
+      int term = MO_MAX_ITERATIONS, iters = 0;
+      for (int i = tid; i < V; i += kThreads) { w.delta[i] = (T)0; w.daff[i] = (T)0; }
+      __syncthreads();
+      // ComputeInitialGuess, qp.cc:439-482
+      if (st == MO_STATUS_OK && sp.initial_guess_method != MO_GUESS_USER_PROVIDED) {
+        for (int i = tid; i < n; i += kThreads) x[i] = (T)0;
+        for (int q = tid; q < k; q += kThreads) y[q] = (T)0;
+        __syncthreads();
+        if (sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED) {     // :455-460
+          eval_kkt(w, n, k, m, false, tid);
+          st = assemble_and_factor(w, n, k, m, false, tid);
+          if (st == MO_STATUS_OK) {
+            solve_for_update(w, n, k, m, (T)0, false, tid);
+            for (int i = tid; i < n; i += kThreads) x[i] = w.delta[i];
+            for (int q = tid; q < k; q += kThreads) y[q] = w.delta[n + m + q];
+          }
+          __syncthreads();
+          load_qp(w, n, k, Gp, G_ld, cp, Ap, a.A_ld, bp, tid);  // the factorisation overwrote G
+        }
+        for (int v = tid; v < n; v += kThreads) {                                 // :464-467 ClampX in constraint order
+          T xv = x[v];
+          for (int c = 0; c < m; ++c) {
+            if (w.cv[c] == v) {
+              const T ca = w.ca[c], cb = w.cb[c];
+              if (ca < (T)0) { const T lim = cb / -ca; xv = xv < lim ? xv : lim; }
+              else { const T lim = -cb / ca; xv = xv > lim ? xv : lim; }
+            }
+          }
+          x[v] = xv;
+        }
+        __syncthreads();
+        for (int c = tid; c < m; c += kThreads) {                                 // :470-481
+          const T sv = w.ca[c] * x[w.cv[c]] + w.cb[c];
+          s[c] = sv > (T)1.0e-9 ? sv : (T)1.0e-9;
+          z[c] = (T)1 / s[c];
+        }
+        __syncthreads();
+      }
+      T mu = (T)sp.initial_mu;
+      if (st == MO_STATUS_OK) {
+        eval_kkt(w, n, k, m, true, tid);                                          // :110
+        if (sp.initialize_mu_with_complementarity) { compute_mu(w, n, k, m, tid); mu = w.red[4]; }  // :115
+      }
+      T* iter_out = a.iterations ? (T*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
+      for (int it = 0; st == MO_STATUS_OK && it < sp.max_iterations; ++it) {
+        T rec[MO_ITER_RECORD];
+        compute_errors(w, n, k, m, mu, tid);                                      // :118
+        rec[0] = w.red[0]; rec[1] = w.red[1]; rec[2] = w.red[2]; rec[3] = w.red[3];
+        __syncthreads();
+        // Iterate, qp.cc:153-201 (its leading EvaluateKKTConditions would recompute the residual we already hold)
+        st = newton_direction(w, n, k, m, mu, sp.barrier_strategy, (T)0.995, rec + 8, tid);
+        if (st != MO_STATUS_OK) break;
+        update_state(w, n, k, m, rec[9], rec[10], tid);
+        load_qp(w, n, k, Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
+        eval_kkt(w, n, k, m, true, tid);                                          // :125
+        compute_errors(w, n, k, m, mu, tid);                                      // :127
+        rec[4] = w.red[0]; rec[5] = w.red[1]; rec[6] = w.red[2]; rec[7] = w.red[3];
+        __syncthreads();
+        compute_mu(w, n, k, m, tid);
+        const T cur_mu = w.red[4];
+        if (iter_out && tid == 0) {
+#pragma unroll
+          for (int i = 0; i < MO_ITER_RECORD; ++i) iter_out[(size_t)it * MO_ITER_RECORD + i] = rec[i];
+        }
+        iters = it + 1;
+        T kmax = rec[4];
+        kmax = rec[5] > kmax ? rec[5] : kmax; kmax = rec[6] > kmax ? rec[6] : kmax; kmax = rec[7] > kmax ? rec[7] : kmax;
+        if (kmax < (T)sp.termination_kkt_tol && cur_mu < (T)sp.termination_complementarity_tol) {  // :132-137
+          term = MO_SATISFIED_KKT_TOL;
+          break;
+        }
+        if (kmax <= mu || !sp.decrease_mu_only_on_small_error) {                  // :140-146
+          if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= (T)sp.sigma;
+          else mu = (T)sp.sigma * cur_mu;
+        }
+        __syncthreads();
+      }
+      __syncthreads();
+      T* vp = (T*)a.vars + p * a.vars_stride;
+      for (int i = tid; i < V; i += kThreads) vp[i] = w.vars[i];
+      if (tid == 0) {
+        if (a.termination) a.termination[p] = term;
+        if (a.num_iterations) a.num_iterations[p] = iters;
+        if (a.status) a.status[p] = st;
+        if (a.lagrange) {                                                         // qp.cc:539-546
+          T mn = nanT<T>(), linf = nanT<T>();
+          if (k > 0) {
+            mn = y[0]; linf = absT(y[0]);
+            for (int q = 1; q < k; ++q) { mn = y[q] < mn ? y[q] : mn; linf = absT(y[q]) > linf ? absT(y[q]) : linf; }
+          }
+          ((T*)a.lagrange)[p * 2] = mn; ((T*)a.lagrange)[p * 2 + 1] = linf;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
+  const size_t e = elem_size == 8 ? ws_elems<double>(a.n, a.k, a.m, a.m_r) : ws_elems<float>(a.n, a.k, a.m, a.m_r);
+  size_t bytes = e * elem_size + (size_t)(a.m + 8) * sizeof(int);
+  return (bytes + 15) & ~(size_t)15;
+}
+
+hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
+  const int elem = dtype == MO_F64 ? 8 : 4;
+  const size_t lds = generic_lds_bytes(a, elem);
+  int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  long long grid = (long long)num_cus * per_cu;
+  if (grid > a.batch) grid = a.batch;
+  if (grid < 1) grid = 1;
+  hipError_t e = hipSuccess;
+#define MO_LAUNCH_GENERIC(TYPE, MODE_)                                                                               \
+  do {                                                                                                               \
+    e = hipFuncSetAttribute((const void*)kkt_generic_kernel<TYPE, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                               \
+    if (e != hipSuccess) return e;                                                                                   \
+    hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_>), dim3((unsigned)grid), dim3(kThreads), lds, stream, a);     \
+  } while (0)
+#define MO_DISPATCH_MODE(TYPE)                                          \
+  switch (a.mode) {                                                     \
+    case MODE_LINEARIZE: MO_LAUNCH_GENERIC(TYPE, MODE_LINEARIZE); break; \
+    case MODE_RESIDUAL: MO_LAUNCH_GENERIC(TYPE, MODE_RESIDUAL); break;   \
+    case MODE_STEP: MO_LAUNCH_GENERIC(TYPE, MODE_STEP); break;           \
+    case MODE_ITERATE: MO_LAUNCH_GENERIC(TYPE, MODE_ITERATE); break;     \
+    case MODE_SOLVE: MO_LAUNCH_GENERIC(TYPE, MODE_SOLVE); break;         \
+    default: return hipErrorInvalidValue;                               \
+  }
+  if (dtype == MO_F64) { MO_DISPATCH_MODE(double) } else { MO_DISPATCH_MODE(float) }
+#undef MO_DISPATCH_MODE
+#undef MO_LAUNCH_GENERIC
+  return hipGetLastError();
+}
+
+}  // namespace mo

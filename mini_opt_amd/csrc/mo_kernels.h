@@ -1,0 +1,62 @@
+// mo_kernels.h -- internal launch interface between the C ABI (mo_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mini_opt_hip.h"
+
+namespace mo {
+
+enum Mode : int {
+  MODE_LINEARIZE = 0,  // nonlinear.cc:182-189 (J^T J, J^T r)
+  MODE_RESIDUAL = 1,   // qp.cc:391-437
+  MODE_STEP = 2,       // qp.cc:391-420, 275-364, 485-507 on the caller's state
+  MODE_ITERATE = 3,    // qp.cc:153-201
+  MODE_SOLVE = 4,      // qp.cc:100-151
+};
+
+// Everything a kernel needs, passed by value (kernarg segment).
+struct KernelArgs {
+  int n, k, m, m_r;
+  int mode;
+  unsigned flags;  // MO_STEP_*
+  long long batch;
+  // problem
+  const void* J; long long J_stride; int J_ld; int J_row_major;
+  const void* r; long long r_stride;
+  double lambda;
+  const void* G; long long G_stride; int G_ld;
+  const void* c; long long c_stride;
+  const void* A; long long A_stride; int A_ld;
+  const void* b; long long b_stride;
+  const int* cons_var; const void* cons_a; const void* cons_b; long long cons_stride;
+  // state
+  void* vars; long long vars_stride;
+  const void* mu; long long mu_stride;
+  double tau;
+  int barrier_strategy;
+  // outputs
+  void* delta; long long delta_stride;
+  void* alpha;     // [batch][2]
+  int* status;     // [batch]
+  void* ip_out;    // [batch][6]
+  void* r_out; long long r_out_stride;  // MODE_RESIDUAL
+  void* kkt_out;   // [batch][4]
+  void* G_out; long long G_out_stride; int G_out_ld;  // MODE_LINEARIZE (also SOLVE scratch for J-level input)
+  void* c_out; long long c_out_stride;
+  void* half_sq_out;
+  // MODE_SOLVE
+  mo_solve_params sp;
+  int* termination; int* num_iterations; void* iterations; void* lagrange;
+};
+
+// shape-generic LDS kernel (any n,k,m,m_r that fits LDS), kkt_generic.hip
+size_t generic_lds_bytes(const KernelArgs& a, int elem_size);
+hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
+
+// fused single-wave MFMA kernels for fixed shapes, kkt_fused.hip.  Returns false if (shape, layout) is unsupported.
+bool fused_supported(const KernelArgs& a, int dtype);
+const char* fused_name(const KernelArgs& a, int dtype);
+hipError_t launch_fused(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
+
+}  // namespace mo

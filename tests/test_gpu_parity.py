@@ -1,0 +1,324 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+ (a) the committed golden fixtures (the reference's own differential tests / KATs), and
+ (b) the CPU oracle on identical seeded inputs.
+Tolerances: fp64 direction within 1e-10 rel-inf of the reference arithmetic (BASELINE.json); the reference's own
+1e-12 absolute bound is used on its small elimination cases; cfg 4 (fp32, no reference counterpart) 2e-3 rel-inf
+against the fp64 oracle on fp32-rounded inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mini_opt_amd import _lib as L
+from mini_opt_amd import qp as Q
+from mini_opt_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL64 = 1e-10
+TOL32 = 2e-3
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def T(a, dt=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev()).contiguous()
+
+
+def qp_from_case(case, dt=torch.float64):
+    """QP-level problem (batch 1) from a JSON fixture; G/A are passed column-major as the ABI expects."""
+    n, k, m = case["n"], case["k"], case["m"]
+    G = np.array(case["G"]).reshape(n, n)
+    A = np.array(case["A_eq"]).reshape(k, n)
+    cons = case["cons"]
+    return Q.BatchedQP(
+        n=n, k=k, m=m, G=T(np.tril(G).T[None], dt), c=T(np.array(case["c"])[None], dt),
+        A_eq=T(A.T[None], dt) if k else None, b_eq=T(np.array(case["b_eq"])[None], dt) if k else None,
+        cons_var=T(np.array([c[0] for c in cons], dtype=np.int32)[None], torch.int32) if m else None,
+        cons_a=T(np.array([c[1] for c in cons])[None], dt) if m else None,
+        cons_b=T(np.array([c[2] for c in cons])[None], dt) if m else None)
+
+
+def batch_to_device(hb, dt=torch.float64):
+    return Q.BatchedQP(n=hb.n, k=hb.k, m=hb.m, J=T(hb.J, dt), r=T(hb.r, dt), lam=hb.lam, A_eq=T(hb.A_eq, dt),
+                       b_eq=T(hb.b_eq, dt), cons_var=T(hb.cons_var, torch.int32), cons_a=T(hb.cons_a, dt),
+                       cons_b=T(hb.cons_b, dt))
+
+
+def rel_inf_rows(got, ref):
+    return np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
+
+
+# ------------------------------------------------------------------ reference differential tests (qp_test.cc:101-241)
+@pytest.mark.parametrize("case", load("elimination.json"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_elimination_cases(case, force_generic):
+    prob = qp_from_case(case)
+    s = Q.QPInteriorPointSolver(prob, force_generic=force_generic)
+    s.SetVariables(T(np.array(case["state"])[None]))
+    r, _ = s.EvaluateKKTConditions(0.0)
+    np.testing.assert_allclose(r.cpu().numpy()[0], case["expected_r"], rtol=0, atol=1e-12)
+    delta, alpha, status = s.NewtonStep(0.0, 0.995)
+    assert int(status[0]) == 0
+    np.testing.assert_allclose(delta.cpu().numpy()[0], case["expected_delta"], rtol=0, atol=case["tol_abs"])
+    # qp_test.cc:141-166: inequalities ignored
+    delta, _, status = s.NewtonStep(0.0, 0.995, include_inequalities=False)
+    assert int(status[0]) == 0
+    d = delta.cpu().numpy()[0]
+    n, k, m = case["n"], case["k"], case["m"]
+    exp = np.array(case["expected_delta_no_ineq_xy"])
+    np.testing.assert_allclose(d[:n], exp[:n], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(d[n + m:n + m + k], exp[n:n + k], rtol=0, atol=1e-12)
+    assert np.all(d[n:n + m] == 0) and np.all(d[n + m + k:] == 0)
+
+
+# ------------------------------------------------------------------ synthetic fixtures (numpy full-system LU)
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4"])
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_synthetic_fixture(cfg, force_generic):
+    z = np.load(os.path.join(GOLDEN, "synthetic.npz"))
+    g = lambda key: z[f"{cfg}_{key}"]
+    f32 = synth.CONFIGS[cfg]["dtype"] == "f32"
+    dt = torch.float32 if f32 else torch.float64
+    J = g("J")
+    B, m_r, n = J.shape
+    k, m = g("b_eq").shape[1], g("cons_var").shape[1]
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J, dt), r=T(g("r"), dt), lam=float(g("lam")), A_eq=T(g("A_eq"), dt),
+                       b_eq=T(g("b_eq"), dt), cons_var=T(g("cons_var"), torch.int32), cons_a=T(g("cons_a"), dt),
+                       cons_b=T(g("cons_b"), dt))
+    s = Q.QPInteriorPointSolver(prob, force_generic=force_generic)
+    s.SetVariables(T(g("vars"), dt))
+    delta, alpha, status = s.NewtonStep(T(g("mu"), dt), 0.995)
+    assert torch.all(status == 0)
+    err = rel_inf_rows(delta.double().cpu().numpy(), g("delta"))
+    assert err.max() < (TOL32 if f32 else TOL64), err
+    # linearisation (a1/a2)
+    G, c, half = Q.linearize(prob)
+    Gl = np.tril(G.double().cpu().numpy()[0].T)
+    np.testing.assert_allclose(Gl, g("G_lower")[0], rtol=1e-5 if f32 else 1e-12, atol=1e-5 if f32 else 1e-12)
+    np.testing.assert_allclose(c.double().cpu().numpy()[0], g("c")[0], rtol=1e-4 if f32 else 1e-12,
+                               atol=1e-4 if f32 else 1e-12)
+    assert np.all(np.triu(G.cpu().numpy()[0].T, 1) == 0)  # strict upper stays exactly 0 (residual_test.cc:130-134)
+    np.testing.assert_allclose(half.double().cpu().numpy(), 0.5 * np.sum(g("r") ** 2, axis=1), rtol=1e-5 if f32 else 1e-13)
+
+
+# ------------------------------------------------------------------ batches vs the oracle
+@pytest.mark.parametrize("cfg,batch", [("cfg1", 257), ("cfg2", 512), ("cfg3", 300), ("cfg4", 64)])
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_batch_vs_oracle(cfg, batch, force_generic):
+    d = synth.CONFIGS[cfg]
+    f32 = d["dtype"] == "f32"
+    dt = torch.float32 if f32 else torch.float64
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], batch, stream=11)
+    if f32:
+        rd = lambda a: a.astype(np.float32).astype(np.float64)
+        for key in ("J", "r", "A_eq", "b_eq", "cons_a", "cons_b", "vars", "mu"):
+            setattr(hb, key, rd(getattr(hb, key)))
+        hb.lam = float(np.float32(hb.lam))
+    s = Q.QPInteriorPointSolver(batch_to_device(hb, dt), force_generic=force_generic)
+    s.SetVariables(T(hb.vars, dt))
+    delta, alpha, status = s.NewtonStep(T(hb.mu, dt), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
+        hb.n, hb.k, hb.m, J=hb.J, r=hb.r, lam=hb.lam, A_eq=hb.A_eq, b_eq=hb.b_eq, cons_var=hb.cons_var, cons_a=hb.cons_a,
+        cons_b=hb.cons_b, vars_=hb.vars, mu=hb.mu)
+    assert np.all(ref_status == 0) and torch.all(status == 0)
+    err = rel_inf_rows(delta.double().cpu().numpy(), ref)
+    assert err.max() < (TOL32 if f32 else TOL64), (err.max(), s.step_kernel())
+    np.testing.assert_allclose(alpha.double().cpu().numpy(), ref_alpha, rtol=0, atol=5e-3 if f32 else 1e-9)
+
+
+def test_qp_level_input_and_shared_constraints():
+    """QP-level (G, c) input with one constraint set shared by the whole batch (stride 0)."""
+    d = synth.CONFIGS["cfg2"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 64, stream=3)
+    G = np.einsum("bqi,bqj->bij", hb.J, hb.J) + hb.lam * np.eye(hb.n)
+    c = np.einsum("bqi,bq->bi", hb.J, hb.r)
+    cv, ca, cb = hb.cons_var[:1], hb.cons_a[:1], hb.cons_b[:1]
+    x = hb.vars[:, :hb.n]
+    sl = (ca * x[:, cv[0]] + cb) * 0.9
+    vars_ = hb.vars.copy()
+    vars_[:, hb.n:hb.n + hb.m] = sl
+    prob = Q.BatchedQP(n=hb.n, k=hb.k, m=hb.m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), A_eq=T(hb.A_eq), b_eq=T(hb.b_eq),
+                       cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    s = Q.QPInteriorPointSolver(prob, batch=64)
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(hb.mu), 0.995)
+    B = 64
+    rep = lambda a: np.repeat(a, B, axis=0)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
+        hb.n, hb.k, hb.m, G=np.tril(G).transpose(0, 2, 1), c=c, A_eq=hb.A_eq, b_eq=hb.b_eq, cons_var=rep(cv), cons_a=rep(ca),
+        cons_b=rep(cb), vars_=vars_, mu=hb.mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < TOL64
+
+
+def test_edge_shapes():
+    """No constraints at all (m = k = 0), equality only, inequality only, tiny n."""
+    rng = np.random.default_rng(5)
+    for (n, k, m, m_r) in [(1, 0, 0, 3), (5, 0, 0, 9), (6, 3, 0, 8), (7, 0, 6, 10), (3, 3, 2, 4), (20, 1, 40, 33)]:
+        B = 9
+        J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+        A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+        cv = rng.integers(0, n, (B, m)).astype(np.int32)
+        ca = rng.choice([-1.0, 1.0, 2.5], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+        x = rng.uniform(-0.1, 0.1, (B, n))
+        sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+        vars_ = np.concatenate([x, sl, y, z], axis=1)
+        mu = np.full(B, 0.05)
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=1e-3, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
+                           cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca) if m else None,
+                           cons_b=T(cb) if m else None)
+        s = Q.QPInteriorPointSolver(prob)
+        s.SetVariables(T(vars_))
+        delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+        ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
+            n, k, m, J=J, r=r, lam=1e-3, A_eq=A if k else None, b_eq=b if k else None, cons_var=cv if m else None,
+            cons_a=ca if m else None, cons_b=cb if m else None, vars_=vars_, mu=mu)
+        assert torch.all(status == 0) and np.all(ref_status == 0), (n, k, m)
+        assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-9, (n, k, m)
+        np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+
+
+def test_status_words():
+    """Per-problem failures never abort the batch: s <= 0 (qp.cc:285), singular KKT (qp.cc:303-307), bad index (qp.cc:70-72)."""
+    d = synth.CONFIGS["cfg1"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 8, stream=2)
+    hb.vars[1, hb.n] = 0.0            # s = 0
+    hb.vars[2, hb.n + 1] = -1.0       # s < 0
+    hb.A_eq[3, :, 1] = hb.A_eq[3, :, 0]  # duplicate equality row -> singular Schur complement (zero pivot, non-zero? no: exact dup)
+    hb.cons_var[4, 0] = hb.n + 3      # out-of-range index
+    hb.J[5, 0, 0] = np.nan
+    s = Q.QPInteriorPointSolver(batch_to_device(hb))
+    s.SetVariables(T(hb.vars))
+    delta, alpha, status = s.NewtonStep(T(hb.mu), 0.995)
+    st = status.cpu().numpy()
+    assert st[0] == 0 and st[6] == 0 and st[7] == 0
+    assert st[1] == L.MO_STATUS_NONPOSITIVE_SLACK and st[2] == L.MO_STATUS_NONPOSITIVE_SLACK
+    assert st[4] == L.MO_STATUS_BAD_INDEX
+    assert st[5] in (L.MO_STATUS_NONFINITE, L.MO_STATUS_FACTORIZATION_FAILED)
+    dn = delta.cpu().numpy()
+    assert np.all(np.isnan(dn[1])) and np.all(np.isnan(dn[4])) and np.all(np.isfinite(dn[0]))
+    # the oracle agrees on the two failure classes the reference defines
+    _, _, ref_status, _ = orc.batched_newton_step(hb.n, hb.k, hb.m, J=hb.J, r=hb.r, lam=hb.lam, A_eq=hb.A_eq, b_eq=hb.b_eq,
+                                                  cons_var=np.clip(hb.cons_var, 0, hb.n - 1), cons_a=hb.cons_a,
+                                                  cons_b=hb.cons_b, vars_=hb.vars, mu=hb.mu)
+    assert ref_status[1] == orc.ORC_NONPOSITIVE_SLACK and ref_status[2] == orc.ORC_NONPOSITIVE_SLACK
+
+
+def test_argument_errors():
+    d = synth.CONFIGS["cfg1"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 4)
+    prob = batch_to_device(hb)
+    s = Q.QPInteriorPointSolver(prob)
+    with pytest.raises(L.MiniOptError):
+        s.NewtonStep(0.1, tau=1.5)
+    with pytest.raises(L.MiniOptError):
+        s.Solve(Q.Params(sigma=0.0))
+    with pytest.raises(L.MiniOptError):
+        s.Solve(Q.Params(max_iterations=0))
+
+
+# ------------------------------------------------------------------ Iterate (qp.cc:153-201) incl. predictor-corrector
+@pytest.mark.parametrize("strategy", [Q.COMPLEMENTARITY, Q.PREDICTOR_CORRECTOR])
+def test_iterate_vs_oracle(strategy):
+    d = synth.CONFIGS["cfg2"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 16, stream=5)
+    s = Q.QPInteriorPointSolver(batch_to_device(hb))
+    s.SetVariables(T(hb.vars))
+    ip, status = s.Iterate(T(hb.mu), strategy)
+    assert torch.all(status == 0)
+    got_vars = s.variables().cpu().numpy()
+    ip = ip.cpu().numpy()
+    for p in range(16):
+        G, c, _ = orc.linearize_dense(hb.J[p], hb.r[p], hb.lam)
+        o = orc.Solver(orc.QP(G=G, c=c, A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=hb.cons_var[p], cons_a=hb.cons_a[p],
+                              cons_b=hb.cons_b[p]))
+        o.variables[:] = hb.vars[p]
+        st, out = o.iterate(float(hb.mu[p]), strategy)
+        assert st == 0
+        assert np.max(np.abs(got_vars[p] - o.variables)) / np.max(np.abs(o.variables)) < 1e-10
+        exp = [out.mu, out.alpha_primal, out.alpha_dual, out.alpha_probe_primal, out.alpha_probe_dual, out.mu_affine]
+        np.testing.assert_allclose(ip[p], exp, rtol=1e-8, atol=1e-12, equal_nan=True)
+
+
+# ------------------------------------------------------------------ full Solve KATs (qp_test.cc:252-471)
+GUESS = {"NAIVE": Q.NAIVE, "SOLVE_EQUALITY_CONSTRAINED": Q.SOLVE_EQUALITY_CONSTRAINED}
+
+
+@pytest.mark.parametrize("case", load("solve_kats.json"), ids=lambda c: c["name"])
+def test_full_solve_kats(case):
+    from tests.test_oracle_golden import check_kat_expectations, qp_from, GUESS as OG, STRAT
+    prob = qp_from_case(case)
+    for guess in case["guesses"]:
+        s = Q.QPInteriorPointSolver(prob)
+        kw = dict(case["params"])
+        kw.pop("barrier_strategy", None)
+        out = s.Solve(Q.Params(initial_guess_method=GUESS[guess], **kw))
+        assert int(out.status[0]) == 0
+        assert int(out.termination_state[0]) == Q.SATISFIED_KKT_TOL, (case["name"], guess)
+        n, k, m = case["n"], case["k"], case["m"]
+        v = s.variables().cpu().numpy()[0]
+        oqp = qp_from(case)
+        check_kat_expectations(case, v[:n], v[n:n + m], v[n + m:n + m + k], v[n + m + k:], oqp)
+        # iteration-by-iteration agreement with the oracle's Solve
+        o = orc.Solver(oqp)
+        term, its = o.solve(initial_guess_method=OG[guess], **kw)
+        assert term == int(out.termination_state[0]) and len(its) == int(out.num_iterations[0])
+        np.testing.assert_allclose(v, o.variables, rtol=1e-7, atol=1e-9)
+        rec = out.iterations.cpu().numpy()[0]
+        for i, it in enumerate(its):
+            exp = [it.kkt_initial.r_dual, it.kkt_initial.r_comp, it.kkt_initial.r_primal_eq, it.kkt_initial.r_primal_ineq,
+                   it.kkt_final.r_dual, it.kkt_final.r_comp, it.kkt_final.r_primal_eq, it.kkt_final.r_primal_ineq,
+                   it.ip.mu, it.ip.alpha_primal, it.ip.alpha_dual]
+            np.testing.assert_allclose(rec[i][:11], exp, rtol=1e-6, atol=1e-9)
+        if k:
+            lag = out.lagrange_multipliers.cpu().numpy()[0]
+            y = o.blocks(o.variables)[2]
+            np.testing.assert_allclose(lag, [y.min(), np.abs(y).max()], rtol=1e-7, atol=1e-9)
+
+
+def test_batched_solve_generated_problems():
+    """Portable restatement of TestGeneratedProblems (qp_test.cc:527-574): the batched device Solve follows the oracle's
+    Solve problem by problem (same iteration counts, same optimum), for both initial-guess methods."""
+    from tests.helpers import generated_qps
+    n = 8
+    by_m = {}
+    for pr in generated_qps(300, n):
+        by_m.setdefault(len(pr[2]), []).append(pr)
+    total = {Q.NAIVE: 0, Q.SOLVE_EQUALITY_CONSTRAINED: 0}
+    for m, group in by_m.items():
+        G = np.stack([np.tril(g[0]).T for g in group])
+        c = np.stack([g[1] for g in group])
+        kw = {}
+        if m:
+            kw = dict(cons_var=T(np.array([[q[0] for q in g[2]] for g in group], dtype=np.int32), torch.int32),
+                      cons_a=T(np.array([[q[1] for q in g[2]] for g in group])),
+                      cons_b=T(np.array([[q[2] for q in g[2]] for g in group])))
+        s = Q.QPInteriorPointSolver(Q.BatchedQP(n=n, k=0, m=m, G=T(G), c=T(c), **kw))
+        for method in (Q.NAIVE, Q.SOLVE_EQUALITY_CONSTRAINED):
+            out = s.Solve(Q.Params(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method))
+            assert torch.all(out.status == 0)
+            x = s.x_block().cpu().numpy()
+            nit = out.num_iterations.cpu().numpy()
+            term = out.termination_state.cpu().numpy()
+            total[method] += int(nit.sum())
+            same = 0
+            for i, (Gi, ci, cons) in enumerate(group):
+                o = orc.Solver(orc.QP(G=Gi, c=ci, cons_var=[q[0] for q in cons], cons_a=[q[1] for q in cons],
+                                      cons_b=[q[2] for q in cons]))
+                t, its = o.solve(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method)
+                if t == term[i] and len(its) == nit[i]:
+                    same += 1
+                    np.testing.assert_allclose(x[i], o.variables[:n], rtol=1e-6, atol=1e-7)
+            assert same >= 0.97 * len(group), (m, method, same, len(group))
+    assert total[Q.SOLVE_EQUALITY_CONSTRAINED] < total[Q.NAIVE]

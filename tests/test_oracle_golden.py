@@ -156,3 +156,48 @@ def test_synthetic_step_vs_numpy_full_system(cfg, use_inverse):
             val, d = v[p][blk], delta[p][blk]
             cand = [-0.995 * val[i] / d[i] for i in range(m) if val[i] + d[i] <= 0 and abs(d[i]) > 0]
             assert abs(a - min([1.0] + cand)) < 1e-12
+
+
+def test_generated_problems_kkt_certificate():
+    """Portable restatement of TestGeneratedProblems (qp_test.cc:527-574): both initial-guess methods run <= 30
+    iterations on random N=8 QPs; every run that reports SATISFIED_KKT_TOL is certified optimal by an independent numpy
+    check of the KKT conditions of the convex QP (stationarity, feasibility, z >= 0, complementarity), and
+    SOLVE_EQUALITY_CONSTRAINED needs fewer iterations in total than NAIVE (qp_test.cc:572-573)."""
+    from tests.helpers import generated_qps
+    n = 8
+    totals = {orc.GUESS_NAIVE: 0, orc.GUESS_SOLVE_EQUALITY_CONSTRAINED: 0}
+    satisfied = 0
+    runs = 0
+    for (G, c, cons) in generated_qps(150, n):
+        for method in totals:
+            s = orc.Solver(orc.QP(G=G, c=c, cons_var=[q[0] for q in cons], cons_a=[q[1] for q in cons],
+                                  cons_b=[q[2] for q in cons]))
+            term, its = s.solve(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method)
+            totals[method] += len(its)
+            runs += 1
+            assert term in (orc.SATISFIED_KKT_TOL, orc.MAX_ITERATIONS)
+            if term != orc.SATISFIED_KKT_TOL:
+                continue
+            satisfied += 1
+            m = len(cons)
+            x, sl, z = s.variables[:n], s.variables[n:n + m], s.variables[n + m:]
+            grad = G @ x + c
+            scale = max(1.0, np.abs(G @ x).max(), np.abs(c).max())
+            for i, (v, a, b) in enumerate(cons):
+                grad[v] -= a * z[i]
+                assert a * x[v] + b >= -1e-9 * max(1.0, abs(b))          # primal feasibility
+                assert z[i] >= 0                                          # dual feasibility
+                assert abs((a * x[v] + b) * z[i]) <= 1e-5 * scale         # complementarity
+            assert np.abs(grad).max() <= 1e-9 * scale                     # stationarity
+    assert satisfied >= 0.5 * runs, (satisfied, runs)  # ill-conditioned draws (cond(G) > 1e7) stop at MAX_ITERATIONS
+    assert totals[orc.GUESS_SOLVE_EQUALITY_CONSTRAINED] < totals[orc.GUESS_NAIVE]
+
+
+def test_predictor_corrector_and_fixed_decrease_converge():
+    """The three BarrierStrategy values (structs.hpp:24-31) all reach the optimum of a KAT problem."""
+    case = [c for c in load("solve_kats.json") if c["name"] == "TestWithInequalitiesAndEqualities"][0]
+    for strat in (orc.COMPLEMENTARITY, orc.FIXED_DECREASE, orc.PREDICTOR_CORRECTOR):
+        s = orc.Solver(qp_from(case))
+        term, its = s.solve(termination_kkt_tol=1e-10, initial_mu=0.1, sigma=0.1, max_iterations=60, barrier_strategy=strat)
+        assert term == orc.SATISFIED_KKT_TOL, strat
+        np.testing.assert_allclose(s.variables[:3], [0.5, -1.0, 2.0], atol=1e-6)
