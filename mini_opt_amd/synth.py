@@ -98,3 +98,46 @@ def algorithmic_bytes(n: int, k: int, m: int, m_r: int, T: int) -> int:
 def algorithmic_flops(n: int, k: int, m: int, m_r: int) -> float:
     P = n + k
     return m_r * n * (n + 1) + 2 * m_r * n + 2 * n * n + 4 * k * n + 6 * m + P ** 3 / 3 + 2 * P * P + 8 * m
+
+
+def make_batch_torch(n: int, k: int, m: int, m_r: int, batch: int, device, dtype, seed: int = SEED):
+    """Device-side generator with the same construction as make_batch (different random stream).
+    Returns (BatchedQP, vars [B,V], mu [B]) resident on `device`."""
+    import torch
+
+    from .qp import BatchedQP
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def U(lo, hi, *shape):
+        return torch.rand(*shape, generator=g, device=device, dtype=torch.float64) * (hi - lo) + lo
+
+    h = m // 2
+    J = torch.empty(batch, m_r, n, device=device, dtype=dtype)
+    step = max(1, (1 << 27) // max(1, m_r * n))  # generate in slices to bound the fp64 temporary
+    for b0 in range(0, batch, step):
+        b1 = min(batch, b0 + step)
+        J[b0:b1] = U(-1, 1, b1 - b0, m_r, n).to(dtype)
+    r = U(-1, 1, batch, m_r).to(dtype)
+    A_eq = U(-1, 1, batch, n, k).to(dtype)
+    b_eq = U(-1, 1, batch, k).to(dtype)
+    v = torch.argsort(torch.rand(batch, n, generator=g, device=device), dim=1)[:, :h]
+    lo = U(-2.0, -0.5, batch, h)
+    hi = U(0.5, 2.0, batch, h)
+    var = torch.cat([v, v], dim=1)
+    a = torch.cat([torch.ones(batch, h, device=device, dtype=torch.float64), -torch.ones(batch, h, device=device, dtype=torch.float64)], dim=1)
+    b = torch.cat([-lo, hi], dim=1)
+    perm = torch.argsort(torch.rand(batch, m, generator=g, device=device), dim=1)
+    cons_var = torch.gather(var, 1, perm).to(torch.int32).contiguous()
+    cons_a = torch.gather(a, 1, perm).to(dtype).contiguous()
+    cons_b = torch.gather(b, 1, perm).to(dtype).contiguous()
+    x = U(-0.4, 0.4, batch, n).to(dtype)
+    xv = torch.gather(x.double(), 1, cons_var.long())
+    s = ((cons_a.double() * xv + cons_b.double()) * U(0.5, 1.5, batch, m)).to(dtype)
+    z = U(0.1, 2.0, batch, m).to(dtype)
+    y = U(-1, 1, batch, k).to(dtype)
+    vars_ = torch.cat([x, s, y, z], dim=1).contiguous()
+    mu = (0.1 * torch.sum(s.double() * z.double(), dim=1) / max(m, 1)).to(dtype).contiguous()
+    qp = BatchedQP(n=n, k=k, m=m, J=J, r=r.contiguous(), lam=LAMBDA, A_eq=A_eq.contiguous(), b_eq=b_eq.contiguous(),
+                   cons_var=cons_var, cons_a=cons_a, cons_b=cons_b)
+    return qp, vars_, mu
