@@ -24,6 +24,7 @@
 //
 // Roofline: per problem 73.6 KB of algorithmic HBM traffic and 440 f64 MFMAs (320 for J^T J at n = 64); see DESIGN.md.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mo_kernels.h"
 
@@ -32,6 +33,21 @@ namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Phase stamps exist only in the diagnostic build of tools/phase_timer.hip; the product kernel executes none.
+#ifdef MO_FUSED_STAMPS
+#define MO_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t__;                                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                       \
+    stamp_acc[i] += t__ - stamp_prev;                                                                 \
+    stamp_prev = t__;                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define MO_STAMP(i) do { } while (0)
+#endif
 
 constexpr int kRC = 15;  // tile column that carries the right-hand side in the [A_eq^T | rhs] tile column
 
@@ -50,11 +66,65 @@ __device__ inline double bpermute_f64(int byte_addr, double v) {
 }
 template <int LANE_IN_ROW> __device__ inline double row_bcast(double v) {  // every lane of a 16-lane row <- lane LANE_IN_ROW
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + LANE_IN_ROW, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + LANE_IN_ROW, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + LANE_IN_ROW, 0xf, 0xf, false);  // all lanes written: no "old" value to set up
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + LANE_IN_ROW, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ inline double xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ inline double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum / min over the 16 lanes of each row, result in every lane of the row.  DPP only (no LDS crossbar):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+__device__ inline double row_sum(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return v;
+}
+__device__ inline double row_min(double v) {
+  v = fmin(v, dpp_f64<0xB1>(v));
+  v = fmin(v, dpp_f64<0x4E>(v));
+  v = fmin(v, dpp_f64<0x141>(v));
+  v = fmin(v, dpp_f64<0x140>(v));
+  return v;
+}
+// v_permlane16_swap(a, b) -> {[a.R0, b.R0, a.R2, b.R2], [a.R1, b.R1, a.R3, b.R3]};  v_permlane32_swap(a, b) ->
+// {[a.R0, a.R1, b.R0, b.R1], [a.R2, a.R3, b.R2, b.R3]}  (R = 16-lane row; verified by tools/microbench.hip).
+struct Rows2 { double a, b; };
+__device__ inline Rows2 swap16_f64(double v) {
+  const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return Rows2{__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+__device__ inline Rows2 swap32_f64(double v) {
+  const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return Rows2{__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+}
+// Sum / min over the four rows (same lane-in-row), result in all four rows.
+__device__ inline double cross_row_sum(double v) {
+  const Rows2 p = swap16_f64(v);
+  const double s = p.a + p.b;
+  const Rows2 q = swap32_f64(s);
+  return q.a + q.b;
+}
+__device__ inline double cross_row_min(double v) {
+  const Rows2 p = swap16_f64(v);
+  const double s = fmin(p.a, p.b);
+  const Rows2 q = swap32_f64(s);
+  return fmin(q.a, q.b);
+}
+// Row SG of v replicated into all four rows.
+template <int SG> __device__ inline double bcast_from_row(double v) {
+  const Rows2 p = swap16_f64(v);                  // p.a = [v0,v0,v2,v2], p.b = [v1,v1,v3,v3]
+  const Rows2 q = swap32_f64((SG & 1) ? p.b : p.a);  // q.a = [y0,y1,y0,y1], q.b = [y2,y3,y2,y3]
+  return (SG & 2) ? q.b : q.a;
+}
 __device__ inline double rcp_f64(double d) {
   double q = __builtin_amdgcn_rcp(d);
   q = fma(q, fma(-d, q, 1.0), q);
@@ -69,78 +139,151 @@ __device__ inline d4 mfma4(const d4& a, const d4& b, d4 c) {  // c += A^T-fragme
   return c;
 }
 
+// LDS-DMA: every lane's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * lane (no VGPR destination).
+// hipcc does not count this load: its completion is waited for by hand with wait_vmcnt<N>() (loads retire in order).
+__device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // single-wave workgroup
+
 // Symmetric sweep of pivots 0..NPIV-1 of a symmetric 16x16 tile held in the C/D layout.  Afterwards the swept block holds
 // -T11^-1, the swept x unswept block T11^-1 T12 (the solution for an augmented right-hand-side column) and the unswept
 // block the Schur complement.  Returns false if a pivot is zero or not finite.
-template <int NPIV_MAX>
-__device__ inline bool sweep_tile(d4& T, int npiv, int g, int j, int addr_j, const int (&addr_r)[4]) {
-  bool ok = true;
+// Broadcast flavours (SW): the f64 MFMA and the VALU share one datapath on gfx950 (tools/coissue.hip: beside back-to-back
+// f64 MFMAs a second wave issues only ~1.5 v_fma_f64 per MFMA), so VALU instructions are as precious as MFMAs, while the
+// LDS crossbar (ds_bpermute) is idle but has ~100+ cycles of latency.  0: both broadcasts through ds_bpermute (fewest
+// VALU instructions; wants >= 3-4 waves per SIMD), 1: row k through ds_bpermute, column k through DPP, 2: VALU only.
+template <int K, int SW>
+__device__ inline void sweep_step(d4& T, bool& ok, int g, int j) {
+  constexpr int src_g = K & 3, src_t = K >> 2;
+  const double rowreg = T[src_t];  // every broadcast below is taken before any register of T is modified
+  const double d = readlane_f64(rowreg, 16 * src_g + K);
+  ok = ok && (fabs(d) > 0.0) && (fabs(d) < INFINITY);
+  const double inv = rcp_f64(d);
+  // T(k, j) for this lane's column j, in every row
+  const double rowk = SW == 2 ? bcast_from_row<src_g>(rowreg) : bpermute_f64((16 * src_g + j) * 4, rowreg);
+  const double rk = (j == K) ? -inv : rowk * inv;
+  double f[4];
 #pragma unroll
-  for (int k = 0; k < NPIV_MAX; ++k) {
-    if (k < npiv) {  // wave-uniform
-      constexpr int dummy = 0; (void)dummy;
-      const int src_g = k & 3, src_t = k >> 2;
-      const double rowreg = T[src_t];  // every broadcast below is taken before any register of T is modified
-      const double d = readlane_f64(rowreg, 16 * src_g + k);
-      ok = ok && (fabs(d) > 0.0) && (fabs(d) < INFINITY);
-      const double inv = rcp_f64(d);
-      const double rowk = bpermute_f64(addr_j + 64 * src_g, rowreg);   // T(k, j) for this lane's column j
-      const double rk = (j == k) ? -inv : rowk * inv;
-      double f[4];
+  for (int t = 0; t < 4; ++t)  // T(g + 4t, k): column k of this lane's own rows ( = T(k, g + 4t) by symmetry)
+    f[t] = SW == 0 ? bpermute_f64((16 * src_g + g + 4 * t) * 4, rowreg) : row_bcast<K>(T[t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) f[t] = bpermute_f64(addr_r[t] + 64 * src_g, rowreg);  // T(k, g+4t) = T(g+4t, k)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double a = (j == k) ? 0.0 : T[t];
-        double nv = fma(-f[t], rk, a);
-        if (t == src_t) nv = (g == src_g) ? rk : nv;
-        T[t] = nv;
-      }
-    }
+  for (int t = 0; t < 4; ++t) {
+    const double a0 = (j == K) ? 0.0 : T[t];
+    double nv = fma(-f[t], rk, a0);
+    if (t == src_t) nv = (g == src_g) ? rk : nv;
+    T[t] = nv;
   }
+}
+template <int K, int KEND, int SW> struct SweepLoop {
+  static __device__ inline void run(d4& T, bool& ok, int npiv, int g, int j) {
+    if (K < npiv) sweep_step<K, SW>(T, ok, g, j);  // wave-uniform
+    SweepLoop<K + 1, KEND, SW>::run(T, ok, npiv, g, j);
+  }
+};
+template <int KEND, int SW> struct SweepLoop<KEND, KEND, SW> {
+  static __device__ inline void run(d4&, bool&, int, int, int) {}
+};
+template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int j) {
+  bool ok = true;
+  SweepLoop<0, 16, SW>::run(T, ok, npiv, g, j);
   return ok;
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
-// NT = n / 16 (2 or 4).  k <= 14, m <= 64, m_r % 4 == 0 are checked by fused_supported().
-template <int NT>
-__global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a) {
-  constexpr int N = 16 * NT;
-  constexpr int NB = NT + 1;  // tile blocks incl. the [A_eq^T | rhs] column / y row
-  constexpr int NH = NT / 2;  // 16-byte loads per J row per lane
-  constexpr int PF = NT >= 4 ? 4 : 8;  // J row-groups (4 rows each) in flight per wave (register budget: 256 VGPRs)
+// NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 14, m <= 64, m_r % 4 == 0 are
+// checked by fused_supported().
+template <int NT, int WPS> struct FusedCfg {
+  static constexpr int N = 16 * NT;
+  static constexpr int NH = NT / 2;                 // 16-byte J loads per lane per 4-row group
+  static constexpr int DPS = NH + 1;                // LDS-DMA instructions per 4-row group (J pieces + 32 B of r)
+  static constexpr int SLOT = NH * 1024 + 64;       // ring slot: 4 rows of J (lane-linear) + r[4s..4s+3]
+  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 5 : 8) : 8;  // ring depth (4-row groups in flight per wave), LDS-limited
+  static constexpr int VEC = 5 * N * 8;             // xs, diagS, rhsS, rp, dxs
+  static constexpr int LDS = D * SLOT + VEC;
+};
 
-  __shared__ __attribute__((aligned(16))) double xs[N];     // x, natural order
-  __shared__ __attribute__((aligned(16))) double diagS[N];  // barrier diagonal per variable, natural order
-  __shared__ __attribute__((aligned(16))) double rhsS[N];   // inequality part of the right-hand side per variable, natural order
-  __shared__ __attribute__((aligned(16))) double rp[N];     // right-hand side, permuted order
-  __shared__ __attribute__((aligned(16))) double dxs[N];    // dx, natural order
+// One workgroup of 4*WPS independent waves per CU (so that exactly WPS waves sit on every SIMD).  The waves never
+// synchronise with each other; each owns its slice of the workgroup's LDS.
+template <int NT, int WPS, int SW>
+__global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
+  using C = FusedCfg<NT, WPS>;
+  constexpr int N = C::N, NB = NT + 1, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
+  constexpr int WAVES = 4 * WPS;
+
+  // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads)
+  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* const smem = smem_all + wave * C::LDS;
+  double* const xs = reinterpret_cast<double*>(smem + D * SLOT);  // x, natural order
+  double* const diagS = xs + N;                                   // barrier diagonal per variable, natural order
+  double* const rhsS = diagS + N;                                 // inequality part of the rhs per variable, natural order
+  double* const rp = rhsS + N;                                    // right-hand side, permuted order
+  double* const dxs = rp + N;                                     // dx, natural order
+  const unsigned ring_base = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (low 32 bits of the flat address)
 
   const int k = a.k, m = a.m, m_r = a.m_r;
+#ifdef MO_FUSED_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const unsigned long long stamp_t0 = stamp_prev, stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-  for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
+  // Problems are handed out from a device-wide ticket counter (zeroed on the stream before the launch): the SIMD
+  // arbitrates oldest-wave-first and CUs do not run at identical speed, so a static split leaves 12-30 % of the waves
+  // idle at the end (measured with tools/phase_timer).  Tickets are taken in guided chunks (up to 8 problems while the
+  // queue is long, single problems at the end) because one counter word sustains only ~88 M atomics/s, and the next
+  // chunk is requested at the START of the current chunk's last problem, so the atomic's latency hides under the J stream.
+  const long long total_waves = (long long)gridDim.x * WAVES;
+  auto chunk_for = [&](long long observed) -> int {
+    const long long c = (a.batch - observed) / (4 * total_waves);
+    return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
+  };
+  auto take_ticket = [&](int chunk) -> unsigned long long {
+    unsigned long long t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    return t;
+  };
+  auto uniform64 = [](unsigned long long v) -> long long {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  int chunk = chunk_for(0);
+  long long p = uniform64(take_ticket(chunk));
+  long long chunk_end = p + chunk;
+
+  while (p < a.batch) {
+    const bool last_of_chunk = p + 1 >= chunk_end;  // wave-uniform
+    int next_chunk = 0;
+    unsigned long long next_ticket = 0;
+    if (last_of_chunk) {
+      next_chunk = chunk_for(p);
+      next_ticket = take_ticket(next_chunk);
+    }
     // Lane coordinates are made opaque once per problem so that nothing derived from them (gather addresses, masks,
     // bpermute addresses) is hoisted out of the problem loop and kept live for the whole kernel: the tile registers
-    // need the room (2 waves per SIMD = 256 VGPRs).
-    int lane = threadIdx.x;
+    // need the room.
+    int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4, j = lane & 15;
-    const int addr_j = j * 4;
-    int addr_r[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) addr_r[t] = (g + 4 * t) * 4;
+
     const double* Jp = (const double*)a.J + p * a.J_stride;
-    const double* rp_g = (const double*)a.r + p * a.r_stride;
+    const double* rg = (const double*)a.r + p * a.r_stride;
     const double* vp = (const double*)a.vars + p * a.vars_stride;
     const double mu = a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0;
 
-    // ---- small loads issued first so that they overlap the J stream
-    if (lane < N / 2) {
-      const d2 xv = *(const d2*)(vp + 2 * lane);
-      xs[2 * lane] = xv[0]; xs[2 * lane + 1] = xv[1];
-      diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
-      rhsS[2 * lane] = 0.0; rhsS[2 * lane + 1] = 0.0;
-    }
+    // ---- P0: every small global load of this problem is issued here, ahead of the J stream, so that it retires under it
+    d4 U[NB * NB];
+#pragma unroll
+    for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
+    d2 xv0 = d2{0.0, 0.0};  // x[2 lane], x[2 lane + 1]; parked in registers until the J stream is done
+    if (lane < N / 2) xv0 = *(const d2*)(vp + 2 * lane);
     int cvar = 0; double ca = 1.0, cb = 0.0, cs = 1.0, cz = 0.0;
     bool bad_index = false;
     if (lane < m) {
@@ -149,76 +292,99 @@ __global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a
       cb = ((const double*)a.cons_b)[p * a.cons_stride + lane];
       cs = vp[N + lane];
       cz = vp[N + m + k + lane];
-      bad_index = (cvar < 0) || (cvar >= N);
-      if (bad_index) cvar = 0;
+    }
+    const double yv = (j < k) ? vp[N + m + j] : 0.0;
+    {  // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
+      const double* Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = g + 4 * t;                                  // row of the tile = permuted variable 16c + r
+          const int col = 32 * (c >> 1) + 2 * r + (c & 1);          // its original column
+          U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)col * a.A_ld] : 0.0;
+        }
+      }
+    }
+    // b_eq: raw loads only (any arithmetic on a loaded value here would make hipcc wait for it before the J stream starts)
+    double b_row[4], b_col = 0.0;
+    {
+      const double* bp = k > 0 ? (const double*)a.b + p * a.b_stride : nullptr;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b_row[t] = (g + 4 * t < k) ? bp[g + 4 * t] : 0.0;
+      b_col = (j < k) ? bp[j] : 0.0;
     }
 
-    // ---- P1: stream J once; G = J^T J on the matrix cores (upper block triangle), c = J^T r on the VALU
-    d4 U[NB * NB];
-#pragma unroll
-    for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
+    MO_STAMP(0);
+    // ---- P1: stream J once through the LDS-DMA ring; G = J^T J on the matrix cores (upper block triangle of tiles),
+    //          c = J^T r on the VALU.  Lane (g, j) of 4-row group s fetches J(4s+g, 32h+2j .. +1) and later reads the same
+    //          16 bytes back, so the ring needs no layout: it is a per-lane FIFO that costs no VGPRs.
     double cpart[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
     {
       const int nsteps = m_r >> 2;
-      const double* Jl = Jp + (size_t)g * N + 2 * j;  // row g of a 4-row group, this lane's column pair
-      const double* rl = rp_g + g;
-      d2 buf[PF][NH];
-      double rbuf[PF];
+      const double* Jl = Jp + (size_t)g * N + 2 * j;
+      const double* rl = rg + 2 * lane;  // lanes 0,1 fetch r[4s .. 4s+3]
+      auto issue = [&](int s) {
+        const unsigned dst = ring_base + (unsigned)(s % D) * SLOT;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        if (u < nsteps) {
+        for (int h = 0; h < NH; ++h) dma16(Jl + (size_t)s * 4 * N + 32 * h, dst + h * 1024);
+        if (lane < 2) dma16(rl + 4 * s, dst + NH * 1024);
+      };
+      auto consume = [&](int s) {
+        const char* slot = smem + (s % D) * SLOT;
+        double ops[NT];
 #pragma unroll
-          for (int h = 0; h < NH; ++h) buf[u][h] = *(const d2*)(Jl + (size_t)u * 4 * N + 32 * h);
-          rbuf[u] = rl[4 * u];
+        for (int h = 0; h < NH; ++h) {
+          const d2 v = *(const d2*)(slot + h * 1024 + lane * 16);
+          ops[2 * h] = v[0]; ops[2 * h + 1] = v[1];
         }
-      }
-      for (int s0 = 0; s0 < nsteps; s0 += PF) {
+        const double rq = *(const double*)(slot + NH * 1024 + 8 * g);
+        lds_fence();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
+        if (s + D < nsteps) issue(s + D);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          if (s0 + u < nsteps) {  // wave-uniform
-            double ops[NT];
+        for (int ta = 0; ta < NT; ++ta) {
+          cpart[ta] = fma(ops[ta], rq, cpart[ta]);
 #pragma unroll
-            for (int h = 0; h < NH; ++h) { ops[2 * h] = buf[u][h][0]; ops[2 * h + 1] = buf[u][h][1]; }
-            const double rq = rbuf[u];
-            const int sn = s0 + u + PF;
-            if (sn < nsteps) {
-#pragma unroll
-              for (int h = 0; h < NH; ++h) buf[u][h] = *(const d2*)(Jl + (size_t)sn * 4 * N + 32 * h);
-              rbuf[u] = rl[4 * sn];
-            }
-#pragma unroll
-            for (int ta = 0; ta < NT; ++ta) {
-              cpart[ta] = fma(ops[ta], rq, cpart[ta]);
-#pragma unroll
-              for (int tb = ta; tb < NT; ++tb)
-                U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
-            }
-          }
+          for (int tb = ta; tb < NT; ++tb)
+            U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
         }
+      };
+      for (int s = 0; s < D && s < nsteps; ++s) issue(s);
+      int s = 0;
+      for (; s + D <= nsteps; ++s) {  // D - 1 younger groups stay in flight
+        wait_vmcnt<(D - 1) * DPS>();
+        consume(s);
       }
+      wait_vmcnt<0>();                // tail: everything has been issued
+      for (; s < nsteps; ++s) consume(s);
     }
+    MO_STAMP(1);
     double cvec[NT];  // c = J^T r at permuted position 16c + j (replicated over g)
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-      double v = cpart[c];
-      v += xor_f64(v, 16);
-      v += xor_f64(v, 32);
-      cvec[c] = v;
+      cvec[c] = cross_row_sum(cpart[c]);
     }
 
-    __builtin_amdgcn_sched_barrier(0);
     // ---- P3: per-constraint barrier terms, scattered per variable through LDS (duplicates on one variable accumulate)
-    __syncthreads();  // xs / diagS / rhsS initialised
+    if (lane < N / 2) {
+      xs[2 * lane] = xv0[0]; xs[2 * lane + 1] = xv0[1];
+      diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
+      rhsS[2 * lane] = 0.0; rhsS[2 * lane + 1] = 0.0;
+    }
+    lds_fence();  // xs / diagS / rhsS initialised
+    bad_index = (lane < m) && ((cvar < 0) || (cvar >= N));           // first use of a P0 load: after the J stream
+    if (bad_index) cvar = 0;
     const bool slack_bad = __any((lane < m) && !(cs > 0.0));
     const bool any_bad_index = __any(bad_index);
+    const double cs_inv = rcp_f64(cs);                               // 1/s to ~1 ulp (two Newton steps on v_rcp_f64)
     if (lane < m) {
-      const double zs = cz / cs;
+      const double zs = cz * cs_inv;
       atomicAdd(&diagS[cvar], ca * zs * ca);                         // qp.cc:296
-      atomicAdd(&rhsS[cvar], ca * (cz * (cs - cb) + mu) / cs);        // x+ form of qp.cc:340-341
+      atomicAdd(&rhsS[cvar], ca * (cz * (cs - cb) + mu) * cs_inv);    // x+ form of qp.cc:340-341
     }
-    __syncthreads();
+    lds_fence();
     double dS[NT], rS[NT];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -231,52 +397,36 @@ __global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a
 #pragma unroll
       for (int c = 0; c < NT; ++c) rp[16 * c + j] = rS[c] - cvec[c];
     }
-    __syncthreads();
+    lds_fence();
 
-    // ---- P2: lambda + Sigma on the diagonal tiles (position (r, r): lanes with j == g + 4t)
+    // ---- P2/P4: lambda + Sigma on the diagonal tiles (position (r, r): lanes with j == g + 4t); rhs into column kRC
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // y diagonal tile = [0, -b_eq; -b_eq^T, 0]: (r, kRC) = -b[r], (kRC, q) = -b[q]
+      double v = 0.0;
+      if (j == kRC) v = -b_row[t];            // b_row is 0 for r >= k
+      if (g + 4 * t == kRC) v = -b_col;       // b_col is 0 for j >= k
+      U[NT * NB + NT][t] = v;
+    }
     const double lam = a.lambda > 0.0 ? a.lambda : 0.0;  // nonlinear.cc:187-189
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? (lam + dS[c]) : 0.0;
-    }
-
-    // ---- P4: tile column NT = [A_eq^T | rhs]; y diagonal tile = [0, -b_eq; -b_eq^T, 0]
-    {
-      // keep the 16 gather addresses of this phase from being hoisted out of the problem loop (they would occupy
-      // 32 VGPRs for the whole kernel): make the lane coordinates opaque to loop-invariant code motion
-      const int gq = g, jq = j;
-      const double* Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
-      const double* bp = k > 0 ? (const double*)a.b + p * a.b_stride : nullptr;
-#pragma unroll
-      for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int r = gq + 4 * t;                                 // row of the tile = permuted variable 16c + r
-          const int col = 32 * (c >> 1) + 2 * r + (c & 1);          // its original column
-          double v = 0.0;
-          if (jq < k) v = Ap[jq + (size_t)col * a.A_ld];
-          if (jq == kRC) v = rp[16 * c + r];
-          U[c * NB + NT][t] = v;
-        }
-      }
-#pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int r = gq + 4 * t;
-        double v = 0.0;
-        if (r < k && jq == kRC) v = -bp[r];
-        if (r == kRC && jq < k) v = -bp[jq];
-        U[NT * NB + NT][t] = v;
+        U[c * NB + c][t] += (j == g + 4 * t) ? (lam + dS[c]) : 0.0;
+        const double rv = rp[16 * c + g + 4 * t];
+        if (j == kRC) U[c * NB + NT][t] = rv;
       }
     }
 
+    MO_STAMP(2);
     // ---- P5: block elimination with 16x16 pivot blocks
     __builtin_amdgcn_sched_barrier(0);
     bool ok = true;
 #pragma unroll
     for (int pa = 0; pa < NB; ++pa) {
-      ok = sweep_tile<16>(U[pa * NB + pa], pa < NT ? 16 : k, g, j, addr_j, addr_r) && ok;
+      ok = sweep_tile<SW>(U[pa * NB + pa], pa < NT ? 16 : k, g, j) && ok;
       __builtin_amdgcn_sched_barrier(0);
+      MO_STAMP(3);
 #pragma unroll
       for (int pc = pa + 1; pc < NB; ++pc) {
         d4 negZ = mfma4(U[pa * NB + pa], U[pa * NB + pc], d4{0.0, 0.0, 0.0, 0.0});  // (-T^-1) U_ac  (T^-1 is symmetric)
@@ -284,6 +434,7 @@ __global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a
         for (int pb = pa + 1; pb <= pc; ++pb) U[pb * NB + pc] = mfma4(U[pa * NB + pb], negZ, U[pb * NB + pc]);
         __builtin_amdgcn_sched_barrier(0);  // one panel tile at a time: keeps a single -Z tile live (register pressure)
       }
+      MO_STAMP(4);
     }
 
     __builtin_amdgcn_sched_barrier(0);
@@ -307,18 +458,17 @@ __global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a
         double pt = 0.0;
 #pragma unroll
         for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
-        pt += xor_f64(pt, 1); pt += xor_f64(pt, 2); pt += xor_f64(pt, 4); pt += xor_f64(pt, 8);  // sum over the row's 16 lanes
+        pt = row_sum(pt);                                  // sum over the row's 16 lanes (columns of the tile row)
         vt[t] = row_bcast<kRC>(U[pa * NB + NT][t]) - pt;  // forward-eliminated rhs minus the already solved blocks
       }
       double q = 0.0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);  // (-T^-1) v, summed over this lane's 4 rows
-      q += xor_f64(q, 16);
-      q += xor_f64(q, 32);
-      xb[pa] = -q;
+      xb[pa] = -cross_row_sum(q);
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    MO_STAMP(5);
     // ---- P7: direction, step lengths, status
     double dxv[NT];
 #pragma unroll
@@ -334,24 +484,20 @@ __global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a
 #pragma unroll
       for (int h = 0; h < NH; ++h) { dxs[32 * h + 2 * j] = dxv[2 * h]; dxs[32 * h + 2 * j + 1] = dxv[2 * h + 1]; }
     }
-    __syncthreads();
+    lds_fence();
     double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
     if (lane < m) {
       const double r_pi = ca * xs[cvar] + cb - cs;                                  // qp.cc:416
       dsv = ca * dxs[cvar] + r_pi;                                                  // qp.cc:361
-      dzv = -(cz / cs) * dsv - (1.0 / cs) * (cs * cz - mu);                         // qp.cc:362
+      dzv = -(cz * cs_inv) * dsv - cs_inv * (cs * cz - mu);                         // qp.cc:362
       const double tau = a.tau;
-      if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -tau * cs / dsv;                 // qp.cc:498-503
-      if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -tau * cz / dzv;
+      if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -tau * cs * rcp_f64(dsv);        // qp.cc:498-503
+      if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -tau * cz * rcp_f64(dzv);
       finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double u1 = xor_f64(ap, o), u2 = xor_f64(ad, o);
-      ap = u1 < ap ? u1 : ap;
-      ad = u2 < ad ? u2 : ad;
-    }
-    const double dyv = (j < k) ? (-xb[NT] - vp[N + m + j]) : 0.0;                   // y+ - y
+    ap = cross_row_min(row_min(ap));
+    ad = cross_row_min(row_min(ad));
+    const double dyv = (j < k) ? (-xb[NT] - yv) : 0.0;                              // y+ - y
     finite = finite && (fabs(dyv) < INFINITY);
     int st = MO_STATUS_OK;
     if (!__all(finite)) st = MO_STATUS_NONFINITE;
@@ -381,8 +527,26 @@ __global__ __launch_bounds__(64, 2) void kkt_fused_f64_kernel(const KernelArgs a
       }
       if (a.status) a.status[p] = st;
     }
-    __syncthreads();  // LDS vectors are re-initialised by the next problem
+    lds_fence();  // LDS vectors are re-initialised by the next problem
+    MO_STAMP(6);
+    if (last_of_chunk) {
+      p = uniform64(next_ticket);
+      chunk_end = p + next_chunk;
+    } else {
+      ++p;
+    }
   }
+#ifdef MO_FUSED_STAMPS
+  if ((threadIdx.x & 63) == 0 && a.debug) {
+    for (int i = 0; i < 8; ++i) atomicAdd(a.debug + i, stamp_acc[i]);
+    atomicAdd(a.debug + 8, 1ull);
+    const unsigned long long life = stamp_prev - stamp_t0, rt = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+    atomicMax(a.debug + 9, life);
+    atomicMin(a.debug + 10, life);
+    atomicAdd(a.debug + 11, rt);
+    atomicMax(a.debug + 12, rt);
+  }
+#endif
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -397,21 +561,39 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (!aligned16(a.J) || (a.J_stride & 1)) return false;
   if (!aligned16(a.vars) || (a.vars_stride & 1)) return false;
   if (!aligned16(a.delta) || (a.delta_stride & 1)) return false;
-  if (!a.delta) return false;
+  if (!a.delta || !a.ticket) return false;
   return true;
 }
 
 const char* fused_name(const KernelArgs& a, int) { return a.n == 64 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32"; }
 
 hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t stream) {
-  long long grid = (long long)num_cus * 8;  // 2 waves per SIMD
-  if (grid > a.batch) grid = a.batch;
+  // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
+  static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
+  static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
+  const int wps = a.n == 64 ? (env_wps == 3 ? 3 : 2) : (env_wps == 4 ? 4 : 3);
+  const int sw = (env_sw >= 0 && env_sw <= 2) ? env_sw : 1;
+  long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
+  const long long blocks_needed = (a.batch + 4 * wps - 1) / (4 * wps);
+  if (grid > blocks_needed) grid = blocks_needed;
   if (grid < 1) grid = 1;
+  hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  const dim3 gd((unsigned)grid), bd(256 * wps);
+#define MO_FUSED_LAUNCH(NT_, WPS_, SW_) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, SW_>), gd, bd, 0, stream, a)
+#define MO_FUSED_BY_SW(NT_, WPS_)                     \
+  do {                                                \
+    if (sw == 0) MO_FUSED_LAUNCH(NT_, WPS_, 0);       \
+    else if (sw == 1) MO_FUSED_LAUNCH(NT_, WPS_, 1);  \
+    else MO_FUSED_LAUNCH(NT_, WPS_, 2);               \
+  } while (0)
   if (a.n == 64) {
-    hipLaunchKernelGGL(kkt_fused_f64_kernel<4>, dim3((unsigned)grid), dim3(64), 0, stream, a);
+    if (wps == 3) MO_FUSED_BY_SW(4, 3); else MO_FUSED_BY_SW(4, 2);
   } else {
-    hipLaunchKernelGGL(kkt_fused_f64_kernel<2>, dim3((unsigned)grid), dim3(64), 0, stream, a);
+    if (wps == 3) MO_FUSED_BY_SW(2, 3); else MO_FUSED_BY_SW(2, 4);
   }
+#undef MO_FUSED_BY_SW
+#undef MO_FUSED_LAUNCH
   return hipGetLastError();
 }
 

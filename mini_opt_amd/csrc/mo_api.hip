@@ -38,6 +38,7 @@ struct mo_plan {
   // scratch for mo_qp_solve with J-level input: G [max_batch][n*n], c [max_batch][n]
   void* G_scratch;
   void* c_scratch;
+  unsigned long long* ticket;  // device work counter of the fused kernels (zeroed on the stream before each launch)
 };
 
 namespace {
@@ -87,8 +88,10 @@ int fill_problem(const mo_plan* plan, const mo_problem* prob, int64_t batch, boo
   return MO_OK;
 }
 
-int launch(const mo_plan* plan, const mo::KernelArgs& a, void* stream) {
-  if (a.batch == 0) return MO_OK;
+int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
+  if (a_in.batch == 0) return MO_OK;
+  mo::KernelArgs a = a_in;
+  a.ticket = plan->ticket;
   MO_HIP_CHECK(hipSetDevice(plan->desc.device));
   hipStream_t s = (hipStream_t)stream;
   const bool force_generic = (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
@@ -155,12 +158,18 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   p->elem = desc->dtype == MO_F64 ? 8 : 4;
   p->G_scratch = nullptr;
   p->c_scratch = nullptr;
+  p->ticket = nullptr;
+  if (hipMalloc((void**)&p->ticket, 256) != hipSuccess) {
+    delete p;
+    return fail(MO_ERR_HIP, "hipMalloc of the work counter failed");
+  }
   mo::KernelArgs a;
   memset(&a, 0, sizeof(a));
   a.n = desc->n; a.k = desc->k; a.m = desc->m; a.m_r = desc->m_r;
   p->generic_lds = mo::generic_lds_bytes(a, p->elem);
   if (p->generic_lds > 160 * 1024) {
     const size_t need = p->generic_lds;
+    (void)hipFree(p->ticket);
     delete p;
     return fail(MO_ERR_UNSUPPORTED, "problem needs %zu B of LDS (> 160 KiB)", need);
   }
@@ -172,6 +181,7 @@ int mo_plan_destroy(mo_plan* plan) {
   if (!plan) return MO_OK;
   if (plan->G_scratch) (void)hipFree(plan->G_scratch);
   if (plan->c_scratch) (void)hipFree(plan->c_scratch);
+  if (plan->ticket) (void)hipFree(plan->ticket);
   delete plan;
   return MO_OK;
 }
@@ -181,6 +191,8 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   mo::KernelArgs a;
   if (fill_problem(plan, prob, 1, true, true, &a) != MO_OK) return "invalid";
   a.mode = mo::MODE_STEP;
+  a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned state / output
+  a.ticket = plan->ticket;
   if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype)) return mo::fused_name(a, plan->desc.dtype);
   return "generic";
 }

@@ -48,6 +48,10 @@ struct KernelArgs {
   // MODE_SOLVE
   mo_solve_params sp;
   int* termination; int* num_iterations; void* iterations; void* lagrange;
+  // fused kernel: device work counter (plan-owned, zeroed on the launch stream before every launch)
+  unsigned long long* ticket;
+  // diagnostics only (tools/phase_timer.hip builds kkt_fused.hip with MO_FUSED_STAMPS); NULL in the product
+  unsigned long long* debug;
 };
 
 // shape-generic LDS kernel (any n,k,m,m_r that fits LDS), kkt_generic.hip

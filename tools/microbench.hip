@@ -65,6 +65,19 @@ __global__ void dpp_test(double* out, double* rcp_out, const double* x) {
   rcp_out[threadIdx.x] = q;
 }
 
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__global__ void permlane_test(unsigned* out) {
+  const unsigned x = threadIdx.x;
+  u2v r = __builtin_amdgcn_permlane16_swap(x, x + 1000, false, false);
+  u2v q = __builtin_amdgcn_permlane32_swap(x, x + 1000, false, false);
+  out[threadIdx.x] = r[0]; out[64 + threadIdx.x] = r[1]; out[128 + threadIdx.x] = q[0]; out[192 + threadIdx.x] = q[1];
+  // DPP row ops on lane ids
+  out[256 + threadIdx.x] = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  out[320 + threadIdx.x] = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  out[384 + threadIdx.x] = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  out[448 + threadIdx.x] = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 int main() {
@@ -103,5 +116,17 @@ int main() {
   printf("row_newbcast semantics: %s\n", bad ? "MISMATCH" : "OK");
   double re = 0; for (int i = 0; i < 64; ++i) re = fmax(re, fabs(rq[i] * x[i] - 1.0));
   printf("rcp+1 newton max |q*x-1| = %.3e\n", re);
+  unsigned* du; CK(hipMalloc(&du, 512 * 4));
+  permlane_test<<<1, 64>>>(du);
+  std::vector<unsigned> u(512); CK(hipMemcpy(u.data(), du, 2048, hipMemcpyDeviceToHost));
+  const char* nm[8] = {"permlane16_swap(a=x,b=x+1000).ret0", "permlane16_swap.ret1", "permlane32_swap.ret0", "permlane32_swap.ret1",
+                       "dpp quad_perm[1,0,3,2]", "dpp quad_perm[2,3,0,1]", "dpp row_half_mirror", "dpp row_mirror"};
+  for (int v = 0; v < 8; ++v) {
+    printf("%-36s rows(first lane of each 16-row): ", nm[v]);
+    for (int r = 0; r < 4; ++r) printf("%4u ", u[v * 64 + 16 * r]);
+    printf(" | lanes 0..7: ");
+    for (int l = 0; l < 8; ++l) printf("%u ", u[v * 64 + l]);
+    printf("\n");
+  }
   return 0;
 }

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect rocprofv3 kernel-trace stats and PMC counters (separate passes, as the MI355X guide prescribes) for bench.py.
+# usage: tools/profile_pmc.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
+i=0
+for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "FETCH_SIZE" "WRITE_SIZE" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_F64 SQ_WAVES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 $ROOT/bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  echo "pass $i ($PMC): exit $?"
+done
+python3 - <<PY
+import csv, glob, collections, os
+out = "$OUT"
+for d in sorted(glob.glob(out + "/pmc*/")):
+    for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int)
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            if "kkt_" not in k: continue
+            agg[k[:60]][row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[(k[:60], row["Counter_Name"])] += 1
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                print(f"{os.path.basename(os.path.dirname(d))} {k} {c} per-dispatch {v / cnt[(k, c)]:.6g}")
+PY
