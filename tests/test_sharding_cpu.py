@@ -1,0 +1,70 @@
+"""Multi-GPU path on CPU: the batch shards over ranks with no data-path collective; only the timing barrier and a
+MAX / SUM of scalars cross ranks (gloo, world_size 2).  The per-rank 'step' here is the CPU oracle standing in for the
+device kernel (tests may use the oracle), checked against a single-rank run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mini_opt_amd import sharding, synth
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 65536, 2 ** 20 + 3):
+        for world in (1, 2, 3, 8):
+            ranges = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+                assert a1 == b0
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_dir):
+    from oracle import oracle as orc
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    info = sharding.RankInfo.from_env()
+    sharding.init_process_group(info, "gloo")
+    d = synth.CONFIGS["cfg1"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], total, stream=99)  # every rank regenerates the same batch
+    b0, b1 = sharding.shard_range(total, rank, world)
+    sl = slice(b0, b1)
+    delta, alpha, status, _ = orc.batched_newton_step(
+        hb.n, hb.k, hb.m, J=hb.J[sl], r=hb.r[sl], lam=hb.lam, A_eq=hb.A_eq[sl], b_eq=hb.b_eq[sl], cons_var=hb.cons_var[sl],
+        cons_a=hb.cons_a[sl], cons_b=hb.cons_b[sl], vars_=hb.vars[sl], mu=hb.mu[sl], num_threads=1)
+    np.save(os.path.join(out_dir, f"delta_{rank}.npy"), delta)
+    dist.barrier()
+    t_max, units = sharding.barrier_max_sum(info, 0.5 + rank, b1 - b0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "agg.npy"), np.array([t_max, units]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_matches_single_rank(tmp_path):
+    from oracle import oracle as orc
+    total, world = 37, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"delta_{r}.npy") for r in range(world)])
+    d = synth.CONFIGS["cfg1"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], total, stream=99)
+    ref, _, status, _ = orc.batched_newton_step(hb.n, hb.k, hb.m, J=hb.J, r=hb.r, lam=hb.lam, A_eq=hb.A_eq, b_eq=hb.b_eq,
+                                                cons_var=hb.cons_var, cons_a=hb.cons_a, cons_b=hb.cons_b, vars_=hb.vars, mu=hb.mu,
+                                                num_threads=1)
+    assert np.all(status == 0)
+    np.testing.assert_array_equal(got, ref)  # sharding changes nothing: problems are independent
+    agg = np.load(tmp_path / "agg.npy")
+    assert agg[0] == 1.5 and agg[1] == total  # MAX of the per-rank times, SUM of the per-rank unit counts
