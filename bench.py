@@ -20,6 +20,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # datasheet fp64 matrix = vector rate; tools/microbench.hip measures 64 cycles per v_mfma_f64_16x16x4_f64
+
+
+def measured_traffic_bytes(kernel_name: str, config: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected with tools/profile_pmc.sh):
+    FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports half of wide 16 B/lane streaming reads, MI355X_MICROARCH.md HBM section)
+    + WRITE_SIZE [KB] x 1024.  Only valid for the workload the counters were collected on; otherwise None."""
+    if config != "cfg3" or batch != 65536 or not kernel_name.startswith("fused"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_fused_cfg3_pmc_summary.json")
+    try:
+        with open(path) as f:
+            summ = json.load(f)
+        row = next(v for k, v in summ.items() if "kkt_fused" in k)
+        return float(row["FETCH_SIZE"]) * 1024.0 * 2.0 + float(row["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 
 
 def usable_cores() -> int:
@@ -124,8 +141,11 @@ def main():
                        "kernel": kernel_name, "batch_per_gpu": batch, "n": n, "k": k, "m": m, "m_r": m_r,
                        "parallelism": f"batch-sharded x{info.world_size}, no collectives"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_step": alg_bytes, "kernel_ms": kernel_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(kernel_name, args.config, batch),
+                         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes * batch,
+                         "kernel_ms": kernel_ms,
+                         "fp64_tflops": synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12,
+                         "fp64_frac_of_peak": synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "status_ok": ok, "status_total": batch,
         }
 

@@ -18,8 +18,9 @@ for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   echo "pass $i ($PMC): exit $?"
 done
 python3 - <<PY
-import csv, glob, collections, os
+import csv, glob, collections, os, json
 out = "$OUT"
+summary = {}
 for d in sorted(glob.glob(out + "/pmc*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int)
@@ -31,4 +32,10 @@ for d in sorted(glob.glob(out + "/pmc*/")):
         for k, cs in agg.items():
             for c, v in cs.items():
                 print(f"{os.path.basename(os.path.dirname(d))} {k} {c} per-dispatch {v / cnt[(k, c)]:.6g}")
+                summary.setdefault(k, {})[c] = v / cnt[(k, c)]
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "kkt_" in row["Name"]:
+            summary.setdefault(row["Name"][:60], {})["kernel_stats"] = {k: row[k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")}
+json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 PY
