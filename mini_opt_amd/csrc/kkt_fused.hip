@@ -26,6 +26,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mo_kernels.h"
 
 namespace mo {
@@ -181,9 +183,55 @@ __device__ inline void sweep_step(d4& T, bool& ok, int g, int j) {
     T[t] = nv;
   }
 }
+// 64-bit helpers for the lean sweep (SW == 3): one v_mov_b64_dpp instead of two 32-bit DPP movs, and EXEC-masked v_mov_b64
+// instead of v_cndmask_b32 pairs.  The asm blocks restore EXEC and end with the wait states a following DPP op needs.
+template <int LANE_IN_ROW> __device__ inline double row_bcast64(double v) {
+  return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + LANE_IN_ROW, 0xf, 0xf, false));
+}
+__device__ inline void masked_set(double& dst, double src, unsigned long long mask) {  // dst = src in the lanes of `mask`
+  unsigned long long save;
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[d], %[s]\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+               : [d] "+v"(dst), [sv] "=&s"(save)
+               : [s] "v"(src), [m] "s"(mask));
+}
+__device__ inline void masked_zero4(d4& T, unsigned long long mask) {  // T[0..3] = 0 in the lanes of `mask`
+  unsigned long long save;
+  double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[a], 0\n\tv_mov_b64 %[b], 0\n\tv_mov_b64 %[c], 0\n\t"
+      "v_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+      : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3), [sv] "=&s"(save)
+      : [m] "s"(mask));
+  T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
+}
+template <int K>
+__device__ inline void sweep_step_lean(d4& T, bool& ok, int g, int j) {
+  constexpr int src_g = K & 3, src_t = K >> 2;
+  const unsigned long long mcol = __builtin_amdgcn_ballot_w64(j == K);      // the four lanes of tile column k
+  const unsigned long long mrow = 0xFFFFull << (16 * src_g);                // the 16 lanes of the row group that holds row k
+  const double rowreg = T[src_t];  // every broadcast below is taken before any register of T is modified
+  const double d = readlane_f64(rowreg, 16 * src_g + K);
+  ok = ok && (fabs(d) > 0.0) && (fabs(d) < INFINITY);
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = fma(inv, fma(-d, inv, 1.0), inv);  // one Newton step: |inv d - 1| < 2e-15 (tools/microbench.hip)
+  double rk = bpermute_f64((16 * src_g + j) * 4, rowreg) * inv;  // T(k, j) / d for this lane's column j, in every row
+  masked_set(rk, -inv, mcol);
+  double f[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) f[t] = row_bcast64<K>(T[t]);  // T(g + 4t, k): column k of this lane's own rows
+  masked_zero4(T, mcol);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) T[t] = fma(-f[t], rk, T[t]);
+  double rowk_new = T[src_t];
+  masked_set(rowk_new, rk, mrow);
+  T[src_t] = rowk_new;
+}
 template <int K, int KEND, int SW> struct SweepLoop {
   static __device__ inline void run(d4& T, bool& ok, int npiv, int g, int j) {
-    if (K < npiv) sweep_step<K, SW>(T, ok, g, j);  // wave-uniform
+    if (K < npiv) {  // wave-uniform
+      if (SW == 3) sweep_step_lean<K>(T, ok, g, j);
+      else sweep_step<K, SW>(T, ok, g, j);
+    }
     SweepLoop<K + 1, KEND, SW>::run(T, ok, npiv, g, j);
   }
 };
@@ -204,7 +252,7 @@ template <int NT, int WPS> struct FusedCfg {
   static constexpr int NH = NT / 2;                 // 16-byte J loads per lane per 4-row group
   static constexpr int DPS = NH + 1;                // LDS-DMA instructions per 4-row group (J pieces + 32 B of r)
   static constexpr int SLOT = NH * 1024 + 64;       // ring slot: 4 rows of J (lane-linear) + r[4s..4s+3]
-  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 5 : 8) : 8;  // ring depth (4-row groups in flight per wave), LDS-limited
+  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 8) : 8;  // ring depth (4-row groups in flight per wave), LDS-limited
   static constexpr int VEC = 5 * N * 8;             // xs, diagS, rhsS, rp, dxs
   static constexpr int LDS = D * SLOT + VEC;
 };
@@ -295,14 +343,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     }
     const double yv = (j < k) ? vp[N + m + j] : 0.0;
     {  // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
-      const double* Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
+      // element (row r = g + 4t of block c, column j < k) = A_eq(j, col), col = 32(c>>1) + 2r + (c&1): one per-lane base
+      // pointer (the 2g part) plus a wave-uniform column offset per (c, t)
+      const double* Al = (k > 0 ? (const double*)a.A + p * a.A_stride : nullptr) + j + (size_t)(2 * g) * a.A_ld;
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int r = g + 4 * t;                                  // row of the tile = permuted variable 16c + r
-          const int col = 32 * (c >> 1) + 2 * r + (c & 1);          // its original column
-          U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)col * a.A_ld] : 0.0;
+          const int col_u = 32 * (c >> 1) + 8 * t + (c & 1);        // wave-uniform part of the original column
+          U[c * NB + NT][t] = (j < k) ? Al[(size_t)col_u * a.A_ld] : 0.0;
         }
       }
     }
@@ -324,25 +373,45 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
     {
       const int nsteps = m_r >> 2;
-      const double* Jl = Jp + (size_t)g * N + 2 * j;
-      const double* rl = rg + 2 * lane;  // lanes 0,1 fetch r[4s .. 4s+3]
-      auto issue = [&](int s) {
-        const unsigned dst = ring_base + (unsigned)(s % D) * SLOT;
+      // Running per-lane source pointers (one 64-bit add per group) and compile-time ring slots: the per-group VALU work is
+      // the four J^T r FMAs plus two pointer bumps -- VALU instructions cost as much as MFMAs on this datapath.
+      const char* jsrc = reinterpret_cast<const char*>(Jp + (size_t)g * N + 2 * j);
+      const char* rsrc = reinterpret_cast<const char*>(rg + 2 * lane);  // lanes 0,1 fetch r[4s .. 4s+3]
+      const char* const lane_piece = smem + lane * 16;                  // this lane's 16 bytes inside a 1 KiB DMA piece
+      const char* const r_elem = smem + NH * 1024 + 8 * g;              // r[4s + g] inside a slot
+      auto issue = [&](auto slot_c) {  // DMAs of the next not-yet-issued 4-row group into ring slot slot_c
+        constexpr int sl = decltype(slot_c)::value;
+        const unsigned dst = ring_base + sl * SLOT;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) dma16(Jl + (size_t)s * 4 * N + 32 * h, dst + h * 1024);
-        if (lane < 2) dma16(rl + 4 * s, dst + NH * 1024);
+        for (int h = 0; h < NH; ++h) dma16(jsrc + 256 * h, dst + h * 1024);
+        if (lane < 2) dma16(rsrc, dst + NH * 1024);
+        jsrc += 4 * N * 8;
+        rsrc += 32;
       };
-      auto consume = [&](int s) {
-        const char* slot = smem + (s % D) * SLOT;
+      auto wait_for_oldest = [&](int younger) {  // `younger` groups (DPS DMA instructions each) may stay in flight
+        if (younger >= D - 1) { wait_vmcnt<(D - 1) * DPS>(); return; }
+        switch (younger) {  // tail of the stream (wave-uniform)
+          case 0: wait_vmcnt<0>(); break;
+          case 1: wait_vmcnt<1 * DPS>(); break;
+          case 2: wait_vmcnt<2 * DPS>(); break;
+          case 3: wait_vmcnt<3 * DPS>(); break;
+          case 4: wait_vmcnt<(D > 4 ? 4 : 0) * DPS>(); break;
+          case 5: wait_vmcnt<(D > 5 ? 5 : 0) * DPS>(); break;
+          default: wait_vmcnt<(D > 6 ? 6 : 0) * DPS>(); break;
+        }
+      };
+      auto consume = [&](auto slot_c, int q) {  // 4-row group q sits in ring slot slot_c
+        constexpr int sl = decltype(slot_c)::value;
+        wait_for_oldest(nsteps - 1 - q);
         double ops[NT];
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-          const d2 v = *(const d2*)(slot + h * 1024 + lane * 16);
+          const d2 v = *(const d2*)(lane_piece + sl * SLOT + h * 1024);
           ops[2 * h] = v[0]; ops[2 * h + 1] = v[1];
         }
-        const double rq = *(const double*)(slot + NH * 1024 + 8 * g);
+        const double rq = *(const double*)(r_elem + sl * SLOT);
         lds_fence();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
-        if (s + D < nsteps) issue(s + D);
+        if (q + D < nsteps) issue(slot_c);
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
           cpart[ta] = fma(ops[ta], rq, cpart[ta]);
@@ -351,14 +420,18 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
             U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
         }
       };
-      for (int s = 0; s < D && s < nsteps; ++s) issue(s);
-      int s = 0;
-      for (; s + D <= nsteps; ++s) {  // D - 1 younger groups stay in flight
-        wait_vmcnt<(D - 1) * DPS>();
-        consume(s);
+      static_assert(D <= 8, "ring depth");
+#define MO_FOR_SLOTS(F)                                                                                        \
+  F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+#define MO_ISSUE(u) if (u < D && u < nsteps) issue(std::integral_constant<int, (u < D ? u : 0)>{});
+      MO_FOR_SLOTS(MO_ISSUE)
+#undef MO_ISSUE
+      for (int q0 = 0; q0 < nsteps; q0 += D) {
+#define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume(std::integral_constant<int, (u < D ? u : 0)>{}, q0 + u);
+        MO_FOR_SLOTS(MO_CONSUME)
+#undef MO_CONSUME
       }
-      wait_vmcnt<0>();                // tail: everything has been issued
-      for (; s < nsteps; ++s) consume(s);
+#undef MO_FOR_SLOTS
     }
     MO_STAMP(1);
     double cvec[NT];  // c = J^T r at permuted position 16c + j (replicated over g)
@@ -459,7 +532,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #pragma unroll
         for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
         pt = row_sum(pt);                                  // sum over the row's 16 lanes (columns of the tile row)
-        vt[t] = row_bcast<kRC>(U[pa * NB + NT][t]) - pt;  // forward-eliminated rhs minus the already solved blocks
+        vt[t] = row_bcast64<kRC>(U[pa * NB + NT][t]) - pt;  // forward-eliminated rhs minus the already solved blocks
       }
       double q = 0.0;
 #pragma unroll
@@ -571,8 +644,8 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
   static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
-  const int wps = a.n == 64 ? (env_wps == 3 ? 3 : 2) : (env_wps == 4 ? 4 : 3);
-  const int sw = (env_sw >= 0 && env_sw <= 2) ? env_sw : 1;
+  const int wps = a.n == 64 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);  // measured best: 3 (A/B in DESIGN.md)
+  const int sw = (env_sw >= 0 && env_sw <= 3) ? env_sw : 3;
   long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
   const long long blocks_needed = (a.batch + 4 * wps - 1) / (4 * wps);
   if (grid > blocks_needed) grid = blocks_needed;
@@ -585,7 +658,8 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   do {                                                \
     if (sw == 0) MO_FUSED_LAUNCH(NT_, WPS_, 0);       \
     else if (sw == 1) MO_FUSED_LAUNCH(NT_, WPS_, 1);  \
-    else MO_FUSED_LAUNCH(NT_, WPS_, 2);               \
+    else if (sw == 2) MO_FUSED_LAUNCH(NT_, WPS_, 2);  \
+    else MO_FUSED_LAUNCH(NT_, WPS_, 3);               \
   } while (0)
   if (a.n == 64) {
     if (wps == 3) MO_FUSED_BY_SW(4, 3); else MO_FUSED_BY_SW(4, 2);
