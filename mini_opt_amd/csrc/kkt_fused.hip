@@ -326,7 +326,30 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const double* vp = (const double*)a.vars + p * a.vars_stride;
     const double mu = a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0;
 
-    // ---- P0: every small global load of this problem is issued here, ahead of the J stream, so that it retires under it
+    // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
+    const int nsteps = m_r >> 2;
+    // Running per-lane source pointers (one 64-bit add per group) and compile-time ring slots: the per-group VALU work is
+    // the four J^T r FMAs plus two pointer bumps -- VALU instructions cost as much as MFMAs on this datapath.
+    const char* jsrc = reinterpret_cast<const char*>(Jp + (size_t)g * N + 2 * j);
+    const char* rsrc = reinterpret_cast<const char*>(rg + 2 * lane);  // lanes 0,1 fetch r[4s .. 4s+3]
+    const char* const lane_piece = smem + lane * 16;                  // this lane's 16 bytes inside a 1 KiB DMA piece
+    const char* const r_elem = smem + NH * 1024 + 8 * g;              // r[4s + g] inside a slot
+    auto issue = [&](auto slot_c) {  // DMAs of the next not-yet-issued 4-row group into ring slot slot_c
+      constexpr int sl = decltype(slot_c)::value;
+      const unsigned dst = ring_base + sl * SLOT;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) dma16(jsrc + 256 * h, dst + h * 1024);
+      if (lane < 2) dma16(rsrc, dst + NH * 1024);
+      jsrc += 4 * N * 8;
+      rsrc += 32;
+    };
+    static_assert(D <= 8, "ring depth");
+#define MO_FOR_SLOTS(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+#define MO_ISSUE(u) if (u < D && u < nsteps) issue(std::integral_constant<int, (u < D ? u : 0)>{});
+    MO_FOR_SLOTS(MO_ISSUE)
+#undef MO_ISSUE
+
+    // ---- P0: every small global load of this problem is issued here (behind the ring fill), so that it retires under P1
     d4 U[NB * NB];
 #pragma unroll
     for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
@@ -372,22 +395,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #pragma unroll
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
     {
-      const int nsteps = m_r >> 2;
-      // Running per-lane source pointers (one 64-bit add per group) and compile-time ring slots: the per-group VALU work is
-      // the four J^T r FMAs plus two pointer bumps -- VALU instructions cost as much as MFMAs on this datapath.
-      const char* jsrc = reinterpret_cast<const char*>(Jp + (size_t)g * N + 2 * j);
-      const char* rsrc = reinterpret_cast<const char*>(rg + 2 * lane);  // lanes 0,1 fetch r[4s .. 4s+3]
-      const char* const lane_piece = smem + lane * 16;                  // this lane's 16 bytes inside a 1 KiB DMA piece
-      const char* const r_elem = smem + NH * 1024 + 8 * g;              // r[4s + g] inside a slot
-      auto issue = [&](auto slot_c) {  // DMAs of the next not-yet-issued 4-row group into ring slot slot_c
-        constexpr int sl = decltype(slot_c)::value;
-        const unsigned dst = ring_base + sl * SLOT;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) dma16(jsrc + 256 * h, dst + h * 1024);
-        if (lane < 2) dma16(rsrc, dst + NH * 1024);
-        jsrc += 4 * N * 8;
-        rsrc += 32;
-      };
       auto wait_for_oldest = [&](int younger) {  // `younger` groups (DPS DMA instructions each) may stay in flight
         if (younger >= D - 1) { wait_vmcnt<(D - 1) * DPS>(); return; }
         switch (younger) {  // tail of the stream (wave-uniform)
@@ -420,12 +427,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
             U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
         }
       };
-      static_assert(D <= 8, "ring depth");
-#define MO_FOR_SLOTS(F)                                                                                        \
-  F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
-#define MO_ISSUE(u) if (u < D && u < nsteps) issue(std::integral_constant<int, (u < D ? u : 0)>{});
-      MO_FOR_SLOTS(MO_ISSUE)
-#undef MO_ISSUE
       for (int q0 = 0; q0 < nsteps; q0 += D) {
 #define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume(std::integral_constant<int, (u < D ? u : 0)>{}, q0 + u);
         MO_FOR_SLOTS(MO_CONSUME)
