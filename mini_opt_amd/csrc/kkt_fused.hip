@@ -244,6 +244,139 @@ template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int 
   return ok;
 }
 
+// ---- reusable components ----------------------------------------------------------------------------------------
+// J stream: J (m_r x N, row-major) goes HBM -> LDS ring -> MFMA operand registers exactly once per pass.  Lane (g, j) of
+// 4-row group s fetches J(4s+g, 32h+2j .. +1) and later reads the same 16 bytes back, so the ring needs no layout: it is a
+// per-lane FIFO that costs no VGPRs.  Running per-lane source pointers and compile-time ring slots keep the per-group VALU
+// work at the four J^T r FMAs plus two pointer bumps.
+template <int NT, int D>
+struct JStream {
+  static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, DPS = NH + 1, SLOT = NH * 1024 + 64;
+  static_assert(D >= 2 && D <= 8, "ring depth");
+  const char* jsrc;
+  const char* rsrc;
+  const char* lane_piece;
+  const char* r_elem;
+  unsigned ring_base;
+  int lane, nsteps;
+
+  __device__ inline void init(const double* Jp, const double* rg, const char* smem, unsigned ring_base_, int lane_, int g, int j, int m_r) {
+    jsrc = reinterpret_cast<const char*>(Jp + (size_t)g * N + 2 * j);
+    rsrc = reinterpret_cast<const char*>(rg + 2 * lane_);  // lanes 0,1 fetch r[4s .. 4s+3]
+    lane_piece = smem + lane_ * 16;                          // this lane's 16 bytes inside a 1 KiB DMA piece
+    r_elem = smem + NH * 1024 + 8 * g;                       // r[4s + g] inside a slot
+    ring_base = ring_base_; lane = lane_; nsteps = m_r >> 2;
+  }
+  template <int SL> __device__ inline void issue() {  // DMAs of the next not-yet-issued 4-row group into ring slot SL
+    const unsigned dst = ring_base + SL * SLOT;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dma16(jsrc + 256 * h, dst + h * 1024);
+    if (lane < 2) dma16(rsrc, dst + NH * 1024);
+    jsrc += 4 * N * 8;
+    rsrc += 32;
+  }
+  __device__ inline void wait_for_oldest(int younger) const {  // `younger` groups (DPS DMAs each) may stay in flight
+    if (younger >= D - 1) { wait_vmcnt<(D - 1) * DPS>(); return; }
+    switch (younger) {  // tail of the stream (wave-uniform)
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<1 * DPS>(); break;
+      case 2: wait_vmcnt<(D > 2 ? 2 : 0) * DPS>(); break;
+      case 3: wait_vmcnt<(D > 3 ? 3 : 0) * DPS>(); break;
+      case 4: wait_vmcnt<(D > 4 ? 4 : 0) * DPS>(); break;
+      case 5: wait_vmcnt<(D > 5 ? 5 : 0) * DPS>(); break;
+      default: wait_vmcnt<(D > 6 ? 6 : 0) * DPS>(); break;
+    }
+  }
+  template <int SL> __device__ inline void consume(int q, d4 (&U)[NB * NB], double (&cpart)[NT]) {  // group q sits in slot SL
+    wait_for_oldest(nsteps - 1 - q);
+    double ops[NT];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const d2 v = *(const d2*)(lane_piece + SL * SLOT + h * 1024);
+      ops[2 * h] = v[0]; ops[2 * h + 1] = v[1];
+    }
+    const double rq = *(const double*)(r_elem + SL * SLOT);
+    lds_fence();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
+    if (q + D < nsteps) issue<SL>();
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta) {
+      cpart[ta] = fma(ops[ta], rq, cpart[ta]);
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb)
+        U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+    }
+  }
+#define MO_FOR_SLOTS(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+  __device__ inline void prologue() {  // fill the ring
+#define MO_ISSUE(u) if (u < D && u < nsteps) issue<(u < D ? u : 0)>();
+    MO_FOR_SLOTS(MO_ISSUE)
+#undef MO_ISSUE
+  }
+  __device__ inline void run(d4 (&U)[NB * NB], double (&cpart)[NT]) {  // G tiles += J^T J, cpart += J^T r partials
+    for (int q0 = 0; q0 < nsteps; q0 += D) {
+#define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume<(u < D ? u : 0)>(q0 + u, U, cpart);
+      MO_FOR_SLOTS(MO_CONSUME)
+#undef MO_CONSUME
+    }
+  }
+#undef MO_FOR_SLOTS
+};
+
+// Block LDL^T with 16x16 pivot blocks over the (NT+1) x (NT+1) upper block triangle of tiles (the last block column is
+// [A_eq^T | rhs]).  Afterwards the diagonal tiles hold -T^-1, the off-diagonal tiles their forward-eliminated values.
+template <int NT, int SW>
+__device__ inline bool block_eliminate(d4 (&U)[(NT + 1) * (NT + 1)], int k, int g, int j) {
+  constexpr int NB = NT + 1;
+  bool ok = true;
+#pragma unroll
+  for (int pa = 0; pa < NB; ++pa) {
+    ok = sweep_tile<SW>(U[pa * NB + pa], pa < NT ? 16 : k, g, j) && ok;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pc = pa + 1; pc < NB; ++pc) {
+      d4 negZ = mfma4(U[pa * NB + pa], U[pa * NB + pc], d4{0.0, 0.0, 0.0, 0.0});  // (-T^-1) U_ac  (T^-1 is symmetric)
+#pragma unroll
+      for (int pb = pa + 1; pb <= pc; ++pb) U[pb * NB + pc] = mfma4(U[pa * NB + pb], negZ, U[pb * NB + pc]);
+      __builtin_amdgcn_sched_barrier(0);  // one panel tile at a time: keeps a single -Z tile live (register pressure)
+    }
+  }
+  return ok;
+}
+
+// Backward substitution after block_eliminate; xb[c] = solution at permuted position 16c + j (replicated over g),
+// xb[NT] = the y-block solution in lanes j < k.
+template <int NT>
+__device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k, int j, double (&xb)[NT + 1]) {
+  constexpr int NB = NT + 1;
+  {
+    double v = 0.0;  // sits in column kRC of the swept y tile: element (q, kRC) at lane (q & 3, kRC), register q >> 2
+    const int src = (16 * (j & 3) + kRC) * 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double w = bpermute_f64(src, U[NT * NB + NT][t]);
+      if ((j >> 2) == t) v = w;
+    }
+    xb[NT] = (j < k) ? v : 0.0;
+  }
+#pragma unroll
+  for (int pa = NT - 1; pa >= 0; --pa) {
+    double vt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double pt = 0.0;
+#pragma unroll
+      for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
+      pt = row_sum(pt);                                  // sum over the row's 16 lanes (columns of the tile row)
+      vt[t] = row_bcast64<kRC>(U[pa * NB + NT][t]) - pt;  // forward-eliminated rhs minus the already solved blocks
+    }
+    double q = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);  // (-T^-1) v, summed over this lane's 4 rows
+    xb[pa] = -cross_row_sum(q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- the kernel ------------------------------------------------------------------------------------------------
 // NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 14, m <= 64, m_r % 4 == 0 are
 // checked by fused_supported().
@@ -262,7 +395,7 @@ template <int NT, int WPS> struct FusedCfg {
 template <int NT, int WPS, int SW>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
   using C = FusedCfg<NT, WPS>;
-  constexpr int N = C::N, NB = NT + 1, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
+  constexpr int N = C::N, NB = NT + 1, NH = C::NH, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
 
   // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads)
@@ -327,27 +460,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const double mu = a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0;
 
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
-    const int nsteps = m_r >> 2;
-    // Running per-lane source pointers (one 64-bit add per group) and compile-time ring slots: the per-group VALU work is
-    // the four J^T r FMAs plus two pointer bumps -- VALU instructions cost as much as MFMAs on this datapath.
-    const char* jsrc = reinterpret_cast<const char*>(Jp + (size_t)g * N + 2 * j);
-    const char* rsrc = reinterpret_cast<const char*>(rg + 2 * lane);  // lanes 0,1 fetch r[4s .. 4s+3]
-    const char* const lane_piece = smem + lane * 16;                  // this lane's 16 bytes inside a 1 KiB DMA piece
-    const char* const r_elem = smem + NH * 1024 + 8 * g;              // r[4s + g] inside a slot
-    auto issue = [&](auto slot_c) {  // DMAs of the next not-yet-issued 4-row group into ring slot slot_c
-      constexpr int sl = decltype(slot_c)::value;
-      const unsigned dst = ring_base + sl * SLOT;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) dma16(jsrc + 256 * h, dst + h * 1024);
-      if (lane < 2) dma16(rsrc, dst + NH * 1024);
-      jsrc += 4 * N * 8;
-      rsrc += 32;
-    };
-    static_assert(D <= 8, "ring depth");
-#define MO_FOR_SLOTS(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
-#define MO_ISSUE(u) if (u < D && u < nsteps) issue(std::integral_constant<int, (u < D ? u : 0)>{});
-    MO_FOR_SLOTS(MO_ISSUE)
-#undef MO_ISSUE
+    JStream<NT, D> stream;
+    stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
+    stream.prologue();
 
     // ---- P0: every small global load of this problem is issued here (behind the ring fill), so that it retires under P1
     d4 U[NB * NB];
@@ -394,46 +509,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     double cpart[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
-    {
-      auto wait_for_oldest = [&](int younger) {  // `younger` groups (DPS DMA instructions each) may stay in flight
-        if (younger >= D - 1) { wait_vmcnt<(D - 1) * DPS>(); return; }
-        switch (younger) {  // tail of the stream (wave-uniform)
-          case 0: wait_vmcnt<0>(); break;
-          case 1: wait_vmcnt<1 * DPS>(); break;
-          case 2: wait_vmcnt<2 * DPS>(); break;
-          case 3: wait_vmcnt<3 * DPS>(); break;
-          case 4: wait_vmcnt<(D > 4 ? 4 : 0) * DPS>(); break;
-          case 5: wait_vmcnt<(D > 5 ? 5 : 0) * DPS>(); break;
-          default: wait_vmcnt<(D > 6 ? 6 : 0) * DPS>(); break;
-        }
-      };
-      auto consume = [&](auto slot_c, int q) {  // 4-row group q sits in ring slot slot_c
-        constexpr int sl = decltype(slot_c)::value;
-        wait_for_oldest(nsteps - 1 - q);
-        double ops[NT];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          const d2 v = *(const d2*)(lane_piece + sl * SLOT + h * 1024);
-          ops[2 * h] = v[0]; ops[2 * h + 1] = v[1];
-        }
-        const double rq = *(const double*)(r_elem + sl * SLOT);
-        lds_fence();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
-        if (q + D < nsteps) issue(slot_c);
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta) {
-          cpart[ta] = fma(ops[ta], rq, cpart[ta]);
-#pragma unroll
-          for (int tb = ta; tb < NT; ++tb)
-            U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
-        }
-      };
-      for (int q0 = 0; q0 < nsteps; q0 += D) {
-#define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume(std::integral_constant<int, (u < D ? u : 0)>{}, q0 + u);
-        MO_FOR_SLOTS(MO_CONSUME)
-#undef MO_CONSUME
-      }
-#undef MO_FOR_SLOTS
-    }
+    stream.run(U, cpart);
     MO_STAMP(1);
     double cvec[NT];  // c = J^T r at permuted position 16c + j (replicated over g)
 #pragma unroll
@@ -514,33 +590,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     __builtin_amdgcn_sched_barrier(0);
     // ---- P6: backward substitution; xb[c] = solution at permuted position 16c + j (replicated over g)
     double xb[NB];
-    {
-      double v = 0.0;  // -y+ sits in column kRC of the swept y tile: element (q, kRC) at lane (q & 3, kRC), register q >> 2
-      const int src = (16 * (j & 3) + kRC) * 4;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double w = bpermute_f64(src, U[NT * NB + NT][t]);
-        if ((j >> 2) == t) v = w;
-      }
-      xb[NT] = (j < k) ? v : 0.0;
-    }
-#pragma unroll
-    for (int pa = NT - 1; pa >= 0; --pa) {
-      double vt[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        double pt = 0.0;
-#pragma unroll
-        for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
-        pt = row_sum(pt);                                  // sum over the row's 16 lanes (columns of the tile row)
-        vt[t] = row_bcast64<kRC>(U[pa * NB + NT][t]) - pt;  // forward-eliminated rhs minus the already solved blocks
-      }
-      double q = 0.0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);  // (-T^-1) v, summed over this lane's 4 rows
-      xb[pa] = -cross_row_sum(q);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    back_substitute<NT>(U, k, j, xb);
 
     MO_STAMP(5);
     // ---- P7: direction, step lengths, status
@@ -623,23 +673,425 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #endif
 }
 
+// =====================================================================================================================
+// Fused interior-point Solve: QPInteriorPointSolver::Solve (qp.cc:100-151) with ComputeInitialGuess
+// (qp.cc:439-482) and Iterate (qp.cc:153-201), one wavefront per QP, per-problem early exit.  Every pass re-streams J
+// (from L2 / HBM) to rebuild the G tiles the previous factorisation consumed, evaluates the KKT residual
+// [G x + c - A^T y - A_i^T z ; A x + b] as a tile product K [x; -y] in registers (qp.cc:404-419), and -- unlike the
+// one-shot step kernel -- solves for the DIRECTION with the residual as right-hand side, exactly the reference's system
+// (qp.cc:255-268, 337-363), so the loop keeps Newton's self-correcting behaviour down to tight KKT tolerances.
+// BarrierStrategy COMPLEMENTARITY and FIXED_DECREASE; PREDICTOR_CORRECTOR runs on the generic kernel.
+template <int NT, int WPS> struct SolveCfg {
+  static constexpr int N = 16 * NT;
+  static constexpr int NH = NT / 2;
+  static constexpr int SLOT = NH * 1024 + 64;
+  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 6) : 8;
+  static constexpr int VEC = (6 * N + 32) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32]
+  static constexpr int LDS = D * SLOT + VEC;
+};
+
+__device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
+
+template <int NT, int WPS, int SW>
+__global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
+  using C = SolveCfg<NT, WPS>;
+  constexpr int N = C::N, NB = NT + 1, NH = C::NH, SLOT = C::SLOT, D = C::D;
+  constexpr int WAVES = 4 * WPS;
+
+  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* const smem = smem_all + wave * C::LDS;
+  double* const xs = reinterpret_cast<double*>(smem + D * SLOT);  // x, natural order
+  double* const xp = xs + N;                                      // x, permuted order
+  double* const azS = xp + N;                                     // sum a z per variable, natural order
+  double* const diagS = azS + N;                                  // barrier diagonal per variable
+  double* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
+  double* const tmp = rhoS + N;                                   // layout-conversion scratch (R <-> V16, natural <-> permuted)
+  double* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
+  const unsigned ring_base = (unsigned)(uintptr_t)smem;
+
+  const int k = a.k, m = a.m, m_r = a.m_r;
+  const mo_solve_params& sp = a.sp;
+
+  const long long total_waves = (long long)gridDim.x * WAVES;
+  auto chunk_for = [&](long long observed) -> int {
+    const long long c = (a.batch - observed) / (4 * total_waves);
+    return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
+  };
+  auto take_ticket = [&](int chunk) -> unsigned long long {
+    unsigned long long t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    return t;
+  };
+  auto uniform64 = [](unsigned long long v) -> long long {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  int chunk = chunk_for(0);
+  long long p = uniform64(take_ticket(chunk));
+  long long chunk_end = p + chunk;
+
+  while (p < a.batch) {
+    const bool last_of_chunk = p + 1 >= chunk_end;
+    int next_chunk = 0;
+    unsigned long long next_ticket = 0;
+    if (last_of_chunk) {
+      next_chunk = chunk_for(p);
+      next_ticket = take_ticket(next_chunk);
+    }
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, j = lane & 15;
+
+    const double* Jp = (const double*)a.J + p * a.J_stride;
+    const double* rg = (const double*)a.r + p * a.r_stride;
+    double* vp = (double*)a.vars + p * a.vars_stride;
+    const double lam = a.lambda > 0.0 ? a.lambda : 0.0;
+
+    // ---- constants of the problem
+    int cvar = 0; double ca = 1.0, cb = 0.0;
+    if (lane < m) {
+      cvar = a.cons_var[p * a.cons_stride + lane];
+      ca = ((const double*)a.cons_a)[p * a.cons_stride + lane];
+      cb = ((const double*)a.cons_b)[p * a.cons_stride + lane];
+    }
+    double b_col = 0.0;
+    if (j < k) b_col = ((const double*)a.b + p * a.b_stride)[j];
+    const double* const Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
+
+    // ---- state: x in the permuted V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
+    double xv[NT], yv = 0.0, cs = 1.0, cz = 1.0;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) xv[c] = 0.0;
+    if (sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { const d2 v = *(const d2*)(vp + 32 * h + 2 * j); xv[2 * h] = v[0]; xv[2 * h + 1] = v[1]; }
+      if (j < k) yv = vp[N + m + j];
+      if (lane < m) { cs = vp[N + lane]; cz = vp[N + m + k + lane]; }
+    }
+    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= N)));
+    if (bad_index) cvar = 0;
+
+    int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
+    int term = MO_MAX_ITERATIONS, it = 0;
+    double mu = sp.initial_mu;
+    bool guess_pass = sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
+    double* iter_out = a.iterations ? (double*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
+
+    // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
+    auto clamp_and_init_slacks = [&]() {
+      if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { xs[32 * h + 2 * j] = xv[2 * h]; xs[32 * h + 2 * j + 1] = xv[2 * h + 1]; }
+      }
+      lds_fence();
+      for (int c = 0; c < m; ++c) {  // wave-uniform loop; one constraint at a time keeps the reference's order
+        if (lane == c) {
+          const double x0 = xs[cvar];
+          double x1;
+          if (ca < 0.0) { const double lim = cb / -ca; x1 = x0 < lim ? x0 : lim; }  // ClampX, qp.hpp:43-53
+          else { const double lim = -cb / ca; x1 = x0 > lim ? x0 : lim; }
+          xs[cvar] = x1;
+        }
+        lds_fence();
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { const d2 v = *(const d2*)(&xs[32 * h + 2 * j]); xv[2 * h] = v[0]; xv[2 * h + 1] = v[1]; }
+      if (lane < m) {
+        const double sv = ca * xs[cvar] + cb;
+        cs = sv > 1.0e-9 ? sv : 1.0e-9;
+        cz = 1.0 / cs;
+      }
+      if (sp.initialize_mu_with_complementarity) {  // qp.cc:115
+        const double t = wave_sum_f64(lane < m ? cs * cz : 0.0);
+        mu = m > 0 ? t / (double)m : 0.0;
+      }
+    };
+    if (st == MO_STATUS_OK && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+
+    double n_rd2 = 0, n_rpe2 = 0, n_rc2 = 0, n_rc1 = 0, n_rpi2 = 0;
+    auto kkt_errors = [&](double mu_e, double (&o)[4]) {  // ComputeErrors, qp.cc:423-437
+      o[0] = sqrt(n_rd2);
+      o[2] = k > 0 ? sqrt(n_rpe2) : 0.0;
+      if (m > 0) {
+        const double corrected = n_rc2 - 2 * (n_rc1 * mu_e) + (mu_e * mu_e) * (double)m;
+        o[1] = sqrt(corrected > 0.0 ? corrected : 0.0);
+        o[3] = sqrt(n_rpi2);
+      } else { o[1] = 0.0; o[3] = 0.0; }
+    };
+    double mu_used = mu;   // the mu handed to the previous Iterate
+    double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
+
+    while (st == MO_STATUS_OK) {
+      const bool include_ineq = !guess_pass;
+      // lane coordinates are re-made opaque every pass: nothing derived from them may be hoisted out of the pass loop and
+      // kept in VGPRs across the factorisation (see the step kernel)
+      int lane_q = threadIdx.x & 63;
+      asm volatile("" : "+v"(lane_q));
+      const int lane = lane_q, g = lane_q >> 4, j = lane_q & 15;  // shadow the per-problem copies inside the pass
+      const double* Al = Ap + j + (size_t)(2 * g) * a.A_ld;
+      // ---------------------------------------------------------------- part A: tiles, residual, norms
+      JStream<NT, D> stream;
+      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
+      stream.prologue();
+      d4 U[NB * NB];
+#pragma unroll
+      for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int col_u = 32 * (c >> 1) + 8 * t + (c & 1);
+          U[c * NB + NT][t] = (j < k) ? Al[(size_t)col_u * a.A_ld] : 0.0;
+        }
+      }
+      // publish the state for the layout conversions below; zero the per-variable scatter arrays
+      if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { xs[32 * h + 2 * j] = xv[2 * h]; xs[32 * h + 2 * j + 1] = xv[2 * h + 1]; }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
+        ysm[j] = (j < k) ? yv : 0.0;
+      }
+      if (lane < N / 2) {
+        azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0;
+        diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
+        rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0;
+      }
+      double cpart[NT];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
+      stream.run(U, cpart);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {  // G = J^T J + lambda I (nonlinear.cc:187-189): lambda is part of G in the residual too
+#pragma unroll
+        for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? lam : 0.0;
+      }
+      double cvec[NT];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+      lds_fence();
+      double r_pi = 0.0, r_comp = 0.0;
+      if (include_ineq && lane < m) {
+        atomicAdd(&azS[cvar], ca * cz);                      // qp.cc:415
+        r_pi = ca * xs[cvar] + cb - cs;                      // qp.cc:416
+        r_comp = cs * cz;                                    // qp.cc:417
+      }
+      // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
+      // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
+      double acc1[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc1[b] = 0.0;
+#pragma unroll
+      for (int ra = 0; ra < NB; ++ra) {
+        double vR[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vR[t] = ra < NT ? xp[16 * ra + g + 4 * t] : -ysm[g + 4 * t];
+#pragma unroll
+        for (int b = ra; b < NB; ++b) {
+          if (ra == NT && b == NT) continue;  // the y diagonal block of K is zero
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc1[b] = fma(U[ra * NB + b][t], vR[t], acc1[b]);
+        }
+        if (ra < NT) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            double pt = 0.0;
+#pragma unroll
+            for (int b = ra + 1; b < NB; ++b) pt = fma(U[ra * NB + b][t], b < NT ? xv[b] : ((j < k) ? -yv : 0.0), pt);
+            pt = row_sum(pt);
+            if (j == 0) tmp[16 * ra + g + 4 * t] = pt;
+          }
+        }
+      }
+      lds_fence();
+      double r_d[NT];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const d2 az = *(const d2*)(&azS[32 * h + 2 * j]);
+        r_d[2 * h] = cross_row_sum(acc1[2 * h]) + tmp[16 * (2 * h) + j] + cvec[2 * h] - az[0];          // qp.cc:404-406, 415
+        r_d[2 * h + 1] = cross_row_sum(acc1[2 * h + 1]) + tmp[16 * (2 * h + 1) + j] + cvec[2 * h + 1] - az[1];
+      }
+      const double r_pe = (j < k) ? cross_row_sum(acc1[NT]) + b_col : 0.0;                                 // qp.cc:408
+      {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t = fma(r_d[c], r_d[c], t);
+        n_rd2 = row_sum(t);
+        n_rpe2 = row_sum(r_pe * r_pe);
+        n_rc2 = wave_sum_f64(r_comp * r_comp);
+        n_rc1 = wave_sum_f64(r_comp);
+        n_rpi2 = wave_sum_f64(r_pi * r_pi);
+        n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
+      }
+      if (!guess_pass) {
+        // ---- the decision point of Solve (qp.cc:116-147)
+        if (it > 0) {
+          double kf[4];
+          kkt_errors(mu_used, kf);                                  // kkt_after of the previous iteration, qp.cc:127
+          const double cur_mu = m > 0 ? n_rc1 / (double)m : 0.0;    // ComputeMu, qp.cc:509-516
+          if (iter_out && lane == 0) {
+            double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
+            rec[4] = kf[0]; rec[5] = kf[1]; rec[6] = kf[2]; rec[7] = kf[3];
+            rec[8] = mu_used; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
+            rec[11] = __builtin_nan(""); rec[12] = __builtin_nan(""); rec[13] = __builtin_nan("");
+          }
+          double kmax = kf[0];
+          kmax = kf[1] > kmax ? kf[1] : kmax; kmax = kf[2] > kmax ? kf[2] : kmax; kmax = kf[3] > kmax ? kf[3] : kmax;
+          if (kmax < sp.termination_kkt_tol && cur_mu < sp.termination_complementarity_tol) {  // qp.cc:132-137
+            term = MO_SATISFIED_KKT_TOL;
+            break;
+          }
+          if (kmax <= mu || !sp.decrease_mu_only_on_small_error) {                             // qp.cc:140-146
+            if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= sp.sigma;
+            else mu = sp.sigma * cur_mu;
+          }
+        }
+        if (it >= sp.max_iterations) break;                          // MAX_ITERATIONS, qp.cc:149
+        double ki[4];
+        kkt_errors(mu, ki);                                          // kkt_prev, qp.cc:118
+        if (iter_out && lane == 0) {
+          double* rec = iter_out + (size_t)it * MO_ITER_RECORD;
+          rec[0] = ki[0]; rec[1] = ki[1]; rec[2] = ki[2]; rec[3] = ki[3];
+        }
+      }
+      // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
+      const double mu_step = m > 0 ? mu : 0.0;                        // qp.cc:165-169
+      double cs_inv = 1.0;
+      if (include_ineq) {
+        if (__any((lane < m) && !(cs > 0.0))) { st = MO_STATUS_NONPOSITIVE_SLACK; break; }  // qp.cc:285
+        cs_inv = rcp_f64(cs);
+        if (lane < m) {
+          const double zs = cz * cs_inv;
+          atomicAdd(&diagS[cvar], ca * zs * ca);                                          // qp.cc:296
+          atomicAdd(&rhoS[cvar], ca * zs * r_pi + ca * (r_comp - mu_step) * cs_inv);      // qp.cc:340-341
+        }
+      }
+      lds_fence();
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const d2 dd = *(const d2*)(&diagS[32 * h + 2 * j]);
+        const d2 rr = *(const d2*)(&rhoS[32 * h + 2 * j]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = 2 * h + e;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? dd[e] : 0.0;
+          if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[e]);          // -r_aug, permuted order (qp.cc:337-342)
+        }
+      }
+      if (g == 0) ysm[16 + j] = -r_pe;
+      lds_fence();
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double rv = tmp[16 * c + g + 4 * t];
+          if (j == kRC) U[c * NB + NT][t] = rv;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // y diagonal tile = [0, -r_pe; -r_pe^T, 0]
+        double v = 0.0;
+        if (j == kRC) v = ysm[16 + g + 4 * t];
+        if (g + 4 * t == kRC) v = -r_pe;
+        U[NT * NB + NT][t] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!block_eliminate<NT, SW>(U, k, g, j)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+      double xb[NB];
+      back_substitute<NT>(U, k, j, xb);      // xb[c] = dx (permuted), xb[NT] = -dy
+      const double dyv = (j < k) ? -xb[NT] : 0.0;
+      bool finite = fabs(dyv) < INFINITY;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
+      if (guess_pass) {                      // qp.cc:455-460: x, y <- the equality-constrained solution
+        if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xv[c] = xb[c];
+        yv = dyv;
+        guess_pass = false;
+        clamp_and_init_slacks();
+        continue;
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { tmp[32 * h + 2 * j] = xb[2 * h]; tmp[32 * h + 2 * j + 1] = xb[2 * h + 1]; }
+      }
+      lds_fence();
+      double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
+      if (lane < m) {
+        dsv = ca * tmp[cvar] + r_pi;                                                   // qp.cc:361
+        dzv = -(cz * cs_inv) * dsv - cs_inv * (r_comp - mu_step);                      // qp.cc:362
+        if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -0.995 * cs * rcp_f64(dsv);       // qp.cc:192, 498-503
+        if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -0.995 * cz * rcp_f64(dzv);
+        finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
+      }
+      if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
+      ap = cross_row_min(row_min(ap));
+      ad = cross_row_min(row_min(ad));
+      // x,s += alpha_p (dx,ds) ; y,z += alpha_d (dy,dz), qp.cc:196-199
+#pragma unroll
+      for (int c = 0; c < NT; ++c) xv[c] = fma(xb[c], ap, xv[c]);
+      yv = fma(dyv, ad, yv);
+      cs = fma(dsv, ap, cs);
+      cz = fma(dzv, ad, cz);
+      mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
+      ++it;
+    }
+
+    // ---- outputs: state, termination, iteration count, Lagrange summary, status
+    if (g == 0) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) { d2 o; o[0] = xv[2 * h]; o[1] = xv[2 * h + 1]; *(d2*)(vp + 32 * h + 2 * j) = o; }
+      if (j < k) vp[N + m + j] = yv;
+    }
+    if (lane < m) { vp[N + lane] = cs; vp[N + m + k + lane] = cz; }
+    const double ymin = row_min((j < k) ? yv : INFINITY), yabs = -row_min((j < k) ? -fabs(yv) : INFINITY);
+    if (lane == 0) {
+      if (a.termination) a.termination[p] = term;
+      if (a.num_iterations) a.num_iterations[p] = it;
+      if (a.status) a.status[p] = st;
+      if (a.lagrange) {  // qp.cc:539-546
+        ((double*)a.lagrange)[2 * p] = k > 0 ? ymin : __builtin_nan("");
+        ((double*)a.lagrange)[2 * p + 1] = k > 0 ? yabs : __builtin_nan("");
+      }
+    }
+    lds_fence();
+    if (last_of_chunk) {
+      p = uniform64(next_ticket);
+      chunk_end = p + next_chunk;
+    } else {
+      ++p;
+    }
+  }
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
 bool fused_supported(const KernelArgs& a, int dtype) {
-  if (dtype != MO_F64 || a.mode != MODE_STEP || a.flags != 0) return false;
+  if (dtype != MO_F64 || a.flags != 0) return false;
+  if (a.mode == MODE_SOLVE) {
+    if (a.sp.barrier_strategy == MO_PREDICTOR_CORRECTOR) return false;
+  } else if (a.mode != MODE_STEP) {
+    return false;
+  }
   if (a.n != 32 && a.n != 64) return false;
   if (a.k > 14 || a.m > 64 || a.m < 0) return false;
   if (!a.J || !a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
   if (!aligned16(a.J) || (a.J_stride & 1)) return false;
   if (!aligned16(a.vars) || (a.vars_stride & 1)) return false;
-  if (!aligned16(a.delta) || (a.delta_stride & 1)) return false;
-  if (!a.delta || !a.ticket) return false;
+  if (a.mode == MODE_STEP && (!a.delta || !aligned16(a.delta) || (a.delta_stride & 1))) return false;
+  if (!a.ticket) return false;
   return true;
 }
 
-const char* fused_name(const KernelArgs& a, int) { return a.n == 64 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32"; }
+const char* fused_name(const KernelArgs& a, int) {
+  if (a.mode == MODE_SOLVE) return a.n == 64 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
+  return a.n == 64 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
+}
 
 hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t stream) {
   // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
@@ -653,6 +1105,17 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
+  if (a.mode == MODE_SOLVE) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
+    const int swps = a.n == 64 ? 2 : 3;
+    long long sgrid = num_cus;
+    const long long need = (a.batch + 4 * swps - 1) / (4 * swps);
+    if (sgrid > need) sgrid = need;
+    if (sgrid < 1) sgrid = 1;
+    const dim3 sgd((unsigned)sgrid), sbd(256 * swps);
+    if (a.n == 64) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3>), sgd, sbd, 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3>), sgd, sbd, 0, stream, a);
+    return hipGetLastError();
+  }
   const dim3 gd((unsigned)grid), bd(256 * wps);
 #define MO_FUSED_LAUNCH(NT_, WPS_, SW_) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, SW_>), gd, bd, 0, stream, a)
 #define MO_FUSED_BY_SW(NT_, WPS_)                     \

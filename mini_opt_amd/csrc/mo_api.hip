@@ -293,7 +293,9 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
   a.sp = *params;
   a.termination = termination; a.num_iterations = num_iterations; a.iterations = iterations; a.lagrange = lagrange;
   a.status = status;
-  if (a.J) {  // the loop re-reads G after every factorisation: keep the linearised G, c in plan scratch
+  a.ticket = plan->ticket;
+  const bool use_fused = !(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype);
+  if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch
     if (batch > plan->desc.max_batch) return fail(MO_ERR_INVALID_ARGUMENT, "batch %lld > plan max_batch %lld", (long long)batch, (long long)plan->desc.max_batch);
     const size_t n = (size_t)plan->desc.n;
     MO_HIP_CHECK(hipSetDevice(plan->desc.device));
@@ -304,10 +306,7 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
     a.G_out = plan->G_scratch; a.G_out_stride = (long long)(n * n); a.G_out_ld = (int)n;
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
   }
-  // the Solve loop only exists in the generic kernel
-  mo_plan tmp = *plan;
-  tmp.desc.flags |= MO_PLAN_FORCE_GENERIC;
-  return launch(&tmp, a, stream);
+  return launch(plan, a, stream);  // fused Solve kernel for J-level n = 32 / 64 fp64 problems, generic kernel otherwise
 }
 
 }  // extern "C"

@@ -340,3 +340,45 @@ def test_fused_kernel_is_selected_for_headline_configs():
         s = Q.QPInteriorPointSolver(batch_to_device(hb))
         assert s.step_kernel() == name
         assert Q.QPInteriorPointSolver(batch_to_device(hb), force_generic=True).step_kernel() == "generic"
+
+
+# ------------------------------------------------------------------ fused on-device Solve (row f1) vs the oracle's Solve
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("guess", [Q.NAIVE, Q.SOLVE_EQUALITY_CONSTRAINED, Q.USER_PROVIDED])
+@pytest.mark.parametrize("strategy", [Q.COMPLEMENTARITY, Q.FIXED_DECREASE])
+def test_fused_solve_vs_oracle(cfg, guess, strategy):
+    """mo_qp_solve on J-level input runs the fused Solve kernel: same termination, iteration count, optimum and per-iteration
+    KKT records as the oracle's restatement of QPInteriorPointSolver::Solve (qp.cc:100-151), problem by problem; the generic
+    kernel must agree as well."""
+    d = synth.CONFIGS[cfg]
+    B = 24
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], B, stream=21)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-9, max_iterations=12, barrier_strategy=strategy,
+              initial_guess_method=guess)
+    results = {}
+    for force in (False, True):
+        s = Q.QPInteriorPointSolver(batch_to_device(hb), force_generic=force)
+        s.SetVariables(T(hb.vars))
+        out = s.Solve(Q.Params(**kw))
+        assert torch.all(out.status == 0)
+        results[force] = (s.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy(),
+                          out.iterations.cpu().numpy(), out.lagrange_multipliers.cpu().numpy())
+    n, k, m = hb.n, hb.k, hb.m
+    for p in range(B):
+        G, c, _ = orc.linearize_dense(hb.J[p], hb.r[p], hb.lam)
+        o = orc.Solver(orc.QP(G=G, c=c, A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=hb.cons_var[p], cons_a=hb.cons_a[p],
+                              cons_b=hb.cons_b[p]))
+        o.variables[:] = hb.vars[p]
+        term, its = o.solve(**kw)
+        for force in (False, True):
+            v, nit, tm, rec, lag = results[force]
+            assert tm[p] == term and nit[p] == len(its), (p, force, tm[p], term, nit[p], len(its))
+            np.testing.assert_allclose(v[p], o.variables, rtol=1e-7, atol=1e-9)
+            scale = max(max(i.kkt_initial.r_dual, i.kkt_initial.r_comp, i.kkt_initial.r_primal_ineq, i.kkt_initial.r_primal_eq) for i in its)
+            for i, itr in enumerate(its):
+                exp = [itr.kkt_initial.r_dual, itr.kkt_initial.r_comp, itr.kkt_initial.r_primal_eq, itr.kkt_initial.r_primal_ineq,
+                       itr.kkt_final.r_dual, itr.kkt_final.r_comp, itr.kkt_final.r_primal_eq, itr.kkt_final.r_primal_ineq,
+                       itr.ip.mu, itr.ip.alpha_primal, itr.ip.alpha_dual]
+                np.testing.assert_allclose(rec[p][i][:11], exp, rtol=1e-6, atol=1e-9 + 1e-12 * scale)
+            y = o.blocks(o.variables)[2]
+            np.testing.assert_allclose(lag[p], [y.min(), np.abs(y).max()], rtol=1e-7, atol=1e-9)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the bench.py contract line): generic-kernel step rate per config and the on-device
+interior-point Solve (row f1) rate.  usage: python tools/bench_modes.py [cfg ...]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+from mini_opt_amd import qp as Q
+from mini_opt_amd import synth
+
+
+def timeit(fn, reps):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps
+
+
+def main():
+    dev = torch.device("cuda:0")
+    for cfg in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
+        d = synth.CONFIGS[cfg]
+        dt = torch.float64 if d["dtype"] == "f64" else torch.float32
+        batch = 8192
+        prob, vars_, mu = synth.make_batch_torch(d["n"], d["k"], d["m"], d["m_r"], batch, dev, dt)
+        out = {"cfg": cfg, "batch": batch}
+        for force in (True, False):
+            s = Q.QPInteriorPointSolver(prob, force_generic=force)
+            s.SetVariables(vars_)
+            t = timeit(lambda: s.NewtonStep(mu, 0.995), 5)
+            out[("generic" if force else s.step_kernel()) + "_step_per_s"] = batch / t
+        s = Q.QPInteriorPointSolver(prob)
+        params = Q.Params(initial_mu=1.0, sigma=0.1, max_iterations=10, termination_kkt_tol=1e-8 if dt == torch.float64 else 1e-3)
+        res = {}
+        def run():
+            res["o"] = s.Solve(params)
+        t = timeit(run, 2)
+        o = res["o"]
+        out["solve_per_s"] = batch / t
+        out["solve_mean_iterations"] = float(o.num_iterations.double().mean())
+        out["solve_satisfied_frac"] = float((o.termination_state == 0).double().mean())
+        out["solve_status_ok_frac"] = float((o.status == 0).double().mean())
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
