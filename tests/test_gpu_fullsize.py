@@ -81,3 +81,37 @@ def test_full_batch_satisfies_newton_equations(cfg, batch):
     err = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
     assert np.all(ref_status == 0) and err.max() < 1e-10, err.max()
     np.testing.assert_allclose(h(a1), ref_alpha, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("cfg,batch", [("cfg2", 4096), ("cfg3", 16384)])
+def test_full_batch_solve_reaches_kkt_point(cfg, batch):
+    """Row f1 at batch scale: the fused on-device Solve terminates with SATISFIED_KKT_TOL for every problem, and the returned
+    state is certified independently (torch fp64): stationarity, primal / dual feasibility and complementarity of the convex QP."""
+    d = synth.CONFIGS[cfg]
+    dev = torch.device("cuda:0")
+    n, k, m = d["n"], d["k"], d["m"]
+    prob, vars_, mu = synth.make_batch_torch(n, k, m, d["m_r"], batch, dev, torch.float64, seed=4321)
+    solver = Q.QPInteriorPointSolver(prob)
+    out = solver.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-9, max_iterations=20,
+                                initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED))
+    assert int((out.status != 0).sum()) == 0
+    assert int((out.termination_state != Q.SATISFIED_KKT_TOL).sum()) == 0
+    assert int(out.num_iterations.max()) <= 20 and int(out.num_iterations.min()) >= 1
+    v = solver.variables().double()
+    x, s, y, z = v[:, :n], v[:, n:n + m], v[:, n + m:n + m + k], v[:, n + m + k:]
+    worst = torch.zeros(4, dtype=torch.float64, device=dev)
+    for b0 in range(0, batch, 4096):
+        sl = slice(b0, min(batch, b0 + 4096))
+        J = prob.J[sl]; r = prob.r[sl]
+        G = torch.bmm(J.transpose(1, 2), J) + prob.lam * torch.eye(n, dtype=torch.float64, device=dev)
+        c = torch.bmm(J.transpose(1, 2), r.unsqueeze(2)).squeeze(2)
+        A = prob.A_eq[sl].transpose(1, 2)
+        var = prob.cons_var[sl].long(); a = prob.cons_a[sl]; bb = prob.cons_b[sl]
+        grad = torch.bmm(G, x[sl].unsqueeze(2)).squeeze(2) + c - torch.bmm(A.transpose(1, 2), y[sl].unsqueeze(2)).squeeze(2)
+        grad = grad - torch.zeros_like(grad).scatter_add_(1, var, a * z[sl])
+        feas_eq = torch.bmm(A, x[sl].unsqueeze(2)).squeeze(2) + prob.b_eq[sl]
+        ci = a * torch.gather(x[sl], 1, var) + bb
+        worst = torch.maximum(worst, torch.stack([grad.abs().max(), feas_eq.abs().max(), (-ci).clamp_min(0).max(), (ci * z[sl]).abs().max()]))
+    w = worst.cpu().numpy()
+    assert w[0] < 1e-8 and w[1] < 1e-8 and w[2] < 1e-8 and w[3] < 1e-4, w   # complementarity tolerance 1e-6 on the mean
+    assert bool((z >= 0).all()) and bool((s > 0).all())

@@ -27,7 +27,7 @@ def main():
     for cfg in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
         d = synth.CONFIGS[cfg]
         dt = torch.float64 if d["dtype"] == "f64" else torch.float32
-        batch = 8192
+        batch = int(os.environ.get("MO_BENCH_BATCH", "8192"))
         prob, vars_, mu = synth.make_batch_torch(d["n"], d["k"], d["m"], d["m_r"], batch, dev, dt)
         out = {"cfg": cfg, "batch": batch}
         for force in (True, False):
