@@ -81,9 +81,14 @@ def main():
     if info.world_size != args.gpus and info.world_size > 1:
         raise SystemExit(f"WORLD_SIZE={info.world_size} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(info.local_rank)
-    dev = torch.device("cuda", info.local_rank)
-    dist = sharding.init_process_group(info, "nccl")
+    # one process per GPU; on a box with fewer GPUs than ranks (rehearsals only) ranks wrap around the visible devices
+    dev_index = info.local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # RCCL ("nccl" on ROCm) carries only the timing barrier and two scalar reductions; MO_BENCH_BACKEND=gloo rehearses the
+    # multi-rank path on a single-GPU box
+    backend = os.environ.get("MO_BENCH_BACKEND", "nccl")
+    dist = sharding.init_process_group(info, backend)
 
     cfg = synth.CONFIGS[args.config]
     n, k, m, m_r = cfg["n"], cfg["k"], cfg["m"], cfg["m_r"]
@@ -116,7 +121,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, dev)
+    elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, dev if backend == "nccl" else None)
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
     ok = int((status == 0).sum().item())

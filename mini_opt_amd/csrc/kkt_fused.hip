@@ -1082,6 +1082,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.k > 14 || a.m > 64 || a.m < 0) return false;
   if (!a.J || !a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
   if (!aligned16(a.J) || (a.J_stride & 1)) return false;
+  if (!aligned16(a.r) || (a.r_stride & 1)) return false;  // r rides in the ring as 16-byte pieces
   if (!aligned16(a.vars) || (a.vars_stride & 1)) return false;
   if (a.mode == MODE_STEP && (!a.delta || !aligned16(a.delta) || (a.delta_stride & 1))) return false;
   if (!a.ticket) return false;
