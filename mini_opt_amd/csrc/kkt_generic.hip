@@ -22,6 +22,21 @@
 
 #include "mo_kernels.h"
 
+// Phase stamps exist only in the diagnostic build of tools/phase_timer_generic.hip; the product kernel executes none.
+#ifdef MO_GENERIC_STAMPS
+#define MO_GSTAMP(i)                                                                              \
+  do {                                                                                            \
+    __syncthreads();                                                                              \
+    if (threadIdx.x == 0) {                                                                       \
+      const unsigned long long t__ = __builtin_amdgcn_s_memtime();                                \
+      gstamp_acc[i] += t__ - gstamp_prev;                                                         \
+      gstamp_prev = t__;                                                                          \
+    }                                                                                             \
+  } while (0)
+#else
+#define MO_GSTAMP(i) do { } while (0)
+#endif
+
 namespace mo {
 namespace {
 
@@ -464,6 +479,9 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
   const int tid = threadIdx.x;
   const bool j_level = a.J != nullptr;
 
+#ifdef MO_GENERIC_STAMPS
+  unsigned long long gstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gstamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
     __syncthreads();  // previous problem's readers are done with LDS
     const T* Jp = j_level ? (const T*)a.J + p * a.J_stride : nullptr;
@@ -495,9 +513,12 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
     if (a.mu) mu_p = ((const T*)a.mu)[p * a.mu_stride];
 
     // cost: QP-level (G, c) or J-level (J, r, lambda)
+    MO_GSTAMP(0);
     load_qp(w, n, k, j_level ? (const T*)nullptr : Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
+    MO_GSTAMP(1);
     if (j_level) {
       accumulate_jtj(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, (T)a.lambda, tid);
+      MO_GSTAMP(2);
       if (MODE == MODE_LINEARIZE || MODE == MODE_SOLVE) {
         // LINEARIZE output, or the per-problem G scratch the Solve loop reloads after each factorisation
         T* Go = (T*)a.G_out + p * a.G_out_stride;
@@ -532,6 +553,7 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
       for (int i = tid; i < V; i += kThreads) { w.delta[i] = (T)0; w.daff[i] = (T)0; }
       if (st == MO_STATUS_OK) {
         eval_kkt(w, n, k, m, !no_ineq, tid);
+        MO_GSTAMP(3);
         if (no_ineq) {
           st = assemble_and_factor(w, n, k, m, false, tid);
           if (st == MO_STATUS_OK) solve_for_update(w, n, k, m, (T)0, false, tid);
@@ -541,6 +563,7 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
           st = newton_direction(w, n, k, m, mu_p, strat, (T)a.tau, ip, tid);
         }
       }
+      MO_GSTAMP(4);
       if (st == MO_STATUS_OK) {  // non-finite direction?
         bool bad = false;
         for (int i = tid; i < V; i += kThreads) bad |= !finiteT(w.delta[i]);
@@ -568,6 +591,7 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
         }
       }
       if (a.status && tid == 0) a.status[p] = st;
+      MO_GSTAMP(6);
       continue;
     }
 
@@ -670,6 +694,11 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
       }
     }
   }
+#ifdef MO_GENERIC_STAMPS
+  if (threadIdx.x == 0 && a.debug) {
+    for (int i = 0; i < 8; ++i) atomicAdd(a.debug + i, gstamp_acc[i]);
+  }
+#endif
 }
 
 }  // namespace
