@@ -763,7 +763,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     double xv[NT], yv = 0.0, cs = 1.0, cz = 1.0;
 #pragma unroll
     for (int c = 0; c < NT; ++c) xv[c] = 0.0;
-    if (sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+    const bool iterate_mode = a.mode == MODE_ITERATE;  // one Iterate (qp.cc:153-201) on the caller's state and mu
+    if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
 #pragma unroll
       for (int h = 0; h < NH; ++h) { const d2 v = *(const d2*)(vp + 32 * h + 2 * j); xv[2 * h] = v[0]; xv[2 * h + 1] = v[1]; }
       if (j < k) yv = vp[N + m + j];
@@ -774,8 +775,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
     int term = MO_MAX_ITERATIONS, it = 0;
-    double mu = sp.initial_mu;
-    bool guess_pass = sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
+    double mu = iterate_mode ? (a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0) : sp.initial_mu;
+    bool guess_pass = !iterate_mode && sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
     double* iter_out = a.iterations ? (double*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
 
     // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         mu = m > 0 ? t / (double)m : 0.0;
       }
     };
-    if (st == MO_STATUS_OK && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+    if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
 
     double n_rd2 = 0, n_rpe2 = 0, n_rc2 = 0, n_rc1 = 0, n_rpi2 = 0;
     auto kkt_errors = [&](double mu_e, double (&o)[4]) {  // ComputeErrors, qp.cc:423-437
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         n_rpi2 = wave_sum_f64(r_pi * r_pi);
         n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
       }
-      if (!guess_pass) {
+      if (!guess_pass && !iterate_mode) {
         // ---- the decision point of Solve (qp.cc:116-147)
         if (it > 0) {
           double kf[4];
@@ -1038,6 +1039,20 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       cz = fma(dzv, ad, cz);
       mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
       ++it;
+      if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
+        if (a.delta) {
+          double* dp = (double*)a.delta + p * a.delta_stride;
+          if (lane < N / 2) { dp[2 * lane] = tmp[2 * lane]; dp[2 * lane + 1] = tmp[2 * lane + 1]; }  // dx, natural order
+          if (lane < m) { dp[N + lane] = dsv; dp[N + m + k + lane] = dzv; }
+          if (g == 0 && j < k) dp[N + m + j] = dyv;
+        }
+        if (a.ip_out && lane == 0) {
+          double* ip = (double*)a.ip_out + p * MO_IP_RECORD;
+          ip[0] = mu; ip[1] = ap; ip[2] = ad;  // outputs.mu = mu_input, qp.cc:160
+          ip[3] = __builtin_nan(""); ip[4] = __builtin_nan(""); ip[5] = __builtin_nan("");
+        }
+        break;
+      }
     }
 
     // ---- outputs: state, termination, iteration count, Lagrange summary, status
@@ -1075,6 +1090,8 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64 || a.flags != 0) return false;
   if (a.mode == MODE_SOLVE) {
     if (a.sp.barrier_strategy == MO_PREDICTOR_CORRECTOR) return false;
+  } else if (a.mode == MODE_ITERATE) {
+    if (a.barrier_strategy == MO_PREDICTOR_CORRECTOR) return false;
   } else if (a.mode != MODE_STEP) {
     return false;
   }
@@ -1090,7 +1107,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
 }
 
 const char* fused_name(const KernelArgs& a, int) {
-  if (a.mode == MODE_SOLVE) return a.n == 64 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
+  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) return a.n == 64 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
   return a.n == 64 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
 }
 
@@ -1106,7 +1123,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  if (a.mode == MODE_SOLVE) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
+  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
     const int swps = a.n == 64 ? 2 : 3;
     long long sgrid = num_cus;
     const long long need = (a.batch + 4 * swps - 1) / (4 * swps);
