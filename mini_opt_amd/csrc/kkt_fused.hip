@@ -141,6 +141,63 @@ __device__ inline d4 mfma4(const d4& a, const d4& b, d4 c) {  // c += A^T-fragme
   return c;
 }
 
+// V16 vector (value at tile position 16c + j) <-> natural-order array.  J-level kernels solve in the pair-permuted variable
+// order the 16-byte J loads induce (position 16c + i <-> variable 32(c>>1) + 2i + (c&1)); QP-level kernels (QPL: G, c given)
+// use the identity, and then nothing needs 16-byte alignment.
+template <int NT, bool QPL> __device__ inline void ldv(const double* arr, int j, double (&v)[NT]) {
+  if (QPL) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) v[c] = arr[16 * c + j];
+  } else {
+#pragma unroll
+    for (int h = 0; h < NT / 2; ++h) { const d2 t = *(const d2*)(arr + 32 * h + 2 * j); v[2 * h] = t[0]; v[2 * h + 1] = t[1]; }
+  }
+}
+template <int NT, bool QPL> __device__ inline void stv(double* arr, int j, const double (&v)[NT]) {
+  if (QPL) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) arr[16 * c + j] = v[c];
+  } else {
+#pragma unroll
+    for (int h = 0; h < NT / 2; ++h) { d2 t; t[0] = v[2 * h]; t[1] = v[2 * h + 1]; *(d2*)(arr + 32 * h + 2 * j) = t; }
+  }
+}
+// [A_eq^T | .] tile column: element (row r = g + 4t of block c, column j < k) = A_eq(j, variable of position 16c + r).
+template <int NT, bool QPL>
+__device__ inline void load_a_tiles(const double* Ap, int A_ld, int k, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)]) {
+  constexpr int NB = NT + 1;
+  const double* Al = Ap + j + (size_t)((QPL ? 1 : 2) * g) * A_ld;  // per-lane part of the column offset
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col_u = QPL ? (16 * c + 4 * t) : (32 * (c >> 1) + 8 * t + (c & 1));  // wave-uniform part
+      U[c * NB + NT][t] = (j < k) ? Al[(size_t)col_u * A_ld] : 0.0;
+    }
+  }
+}
+// QP-level cost: the G tiles come straight from the caller's column-major G (only its lower triangle is read, qp.cc:289):
+// tile (a, b), element (r, j) = G(16b + j, 16a + r) for b > a (128-byte rows across the lanes), mirrored inside diagonal tiles.
+template <int NT>
+__device__ inline void load_g_tiles(const double* G, int ld, const double* cg, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)],
+                                    double (&cvec)[NT]) {
+  constexpr int NB = NT + 1;
+#pragma unroll
+  for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+    for (int tb = ta; tb < NT; ++tb) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = g + 4 * t;
+        int row = 16 * tb + j, col = 16 * ta + r;
+        if (ta == tb && r > j) { row = 16 * ta + r; col = 16 * ta + j; }
+        U[ta * NB + tb][t] = G[row + (size_t)col * ld];
+      }
+    }
+    cvec[ta] = cg[16 * ta + j];
+  }
+}
+
 // LDS-DMA: every lane's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * lane (no VGPR destination).
 // hipcc does not count this load: its completion is waited for by hand with wait_vmcnt<N>() (loads retire in order).
 __device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
@@ -392,10 +449,10 @@ template <int NT, int WPS> struct FusedCfg {
 
 // One workgroup of 4*WPS independent waves per CU (so that exactly WPS waves sit on every SIMD).  The waves never
 // synchronise with each other; each owns its slice of the workgroup's LDS.
-template <int NT, int WPS, int SW>
+template <int NT, int WPS, int SW, bool QPL>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
   using C = FusedCfg<NT, WPS>;
-  constexpr int N = C::N, NB = NT + 1, NH = C::NH, SLOT = C::SLOT, D = C::D;
+  constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
 
   // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads)
@@ -454,22 +511,25 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4, j = lane & 15;
 
-    const double* Jp = (const double*)a.J + p * a.J_stride;
-    const double* rg = (const double*)a.r + p * a.r_stride;
+    const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
+    const double* rg = QPL ? nullptr : (const double*)a.r + p * a.r_stride;
     const double* vp = (const double*)a.vars + p * a.vars_stride;
     const double mu = a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0;
 
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
     JStream<NT, D> stream;
-    stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
-    stream.prologue();
+    if (!QPL) {
+      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
+      stream.prologue();
+    }
 
     // ---- P0: every small global load of this problem is issued here (behind the ring fill), so that it retires under P1
     d4 U[NB * NB];
 #pragma unroll
     for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-    d2 xv0 = d2{0.0, 0.0};  // x[2 lane], x[2 lane + 1]; parked in registers until the J stream is done
-    if (lane < N / 2) xv0 = *(const d2*)(vp + 2 * lane);
+    d2 xv0 = d2{0.0, 0.0};  // x[2 lane], x[2 lane + 1] (QPL: x[lane]); parked in registers until the J stream is done
+    if (QPL) { if (lane < N) xv0[0] = vp[lane]; }
+    else if (lane < N / 2) xv0 = *(const d2*)(vp + 2 * lane);
     int cvar = 0; double ca = 1.0, cb = 0.0, cs = 1.0, cz = 0.0;
     bool bad_index = false;
     if (lane < m) {
@@ -480,19 +540,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       cz = vp[N + m + k + lane];
     }
     const double yv = (j < k) ? vp[N + m + j] : 0.0;
-    {  // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
-      // element (row r = g + 4t of block c, column j < k) = A_eq(j, col), col = 32(c>>1) + 2r + (c&1): one per-lane base
-      // pointer (the 2g part) plus a wave-uniform column offset per (c, t)
-      const double* Al = (k > 0 ? (const double*)a.A + p * a.A_stride : nullptr) + j + (size_t)(2 * g) * a.A_ld;
-#pragma unroll
-      for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int col_u = 32 * (c >> 1) + 8 * t + (c & 1);        // wave-uniform part of the original column
-          U[c * NB + NT][t] = (j < k) ? Al[(size_t)col_u * a.A_ld] : 0.0;
-        }
-      }
-    }
+    // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
+    load_a_tiles<NT, QPL>(k > 0 ? (const double*)a.A + p * a.A_stride : nullptr, a.A_ld, k, g, j, U);
     // b_eq: raw loads only (any arithmetic on a loaded value here would make hipcc wait for it before the J stream starts)
     double b_row[4], b_col = 0.0;
     {
@@ -509,16 +558,20 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     double cpart[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
-    stream.run(U, cpart);
-    MO_STAMP(1);
-    double cvec[NT];  // c = J^T r at permuted position 16c + j (replicated over g)
+    double cvec[NT];  // c (= J^T r) at position 16c + j (replicated over g)
+    if (QPL) {
+      load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, g, j, U, cvec);
+    } else {
+      stream.run(U, cpart);
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      cvec[c] = cross_row_sum(cpart[c]);
+      for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
     }
+    MO_STAMP(1);
 
     // ---- P3: per-constraint barrier terms, scattered per variable through LDS (duplicates on one variable accumulate)
-    if (lane < N / 2) {
+    if (QPL) {
+      if (lane < N) { xs[lane] = xv0[0]; diagS[lane] = 0.0; rhsS[lane] = 0.0; }
+    } else if (lane < N / 2) {
       xs[2 * lane] = xv0[0]; xs[2 * lane + 1] = xv0[1];
       diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
       rhsS[2 * lane] = 0.0; rhsS[2 * lane + 1] = 0.0;
@@ -536,13 +589,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     }
     lds_fence();
     double dS[NT], rS[NT];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const d2 dd = *(const d2*)(&diagS[32 * h + 2 * j]);
-      const d2 rr = *(const d2*)(&rhsS[32 * h + 2 * j]);
-      dS[2 * h] = dd[0]; dS[2 * h + 1] = dd[1];
-      rS[2 * h] = rr[0]; rS[2 * h + 1] = rr[1];
-    }
+    ldv<NT, QPL>(diagS, j, dS);
+    ldv<NT, QPL>(rhsS, j, rS);
     if (g == 0) {
 #pragma unroll
       for (int c = 0; c < NT; ++c) rp[16 * c + j] = rS[c] - cvec[c];
@@ -557,7 +605,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       if (g + 4 * t == kRC) v = -b_col;       // b_col is 0 for j >= k
       U[NT * NB + NT][t] = v;
     }
-    const double lam = a.lambda > 0.0 ? a.lambda : 0.0;  // nonlinear.cc:187-189
+    const double lam = (!QPL && a.lambda > 0.0) ? a.lambda : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
@@ -595,19 +643,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     MO_STAMP(5);
     // ---- P7: direction, step lengths, status
     double dxv[NT];
+    {
+      double xn[NT];
+      ldv<NT, QPL>(xs, j, xn);
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const d2 xv = *(const d2*)(&xs[32 * h + 2 * j]);
-      dxv[2 * h] = xb[2 * h] - xv[0];
-      dxv[2 * h + 1] = xb[2 * h + 1] - xv[1];
+      for (int c = 0; c < NT; ++c) dxv[c] = xb[c] - xn[c];
     }
     bool finite = true;
 #pragma unroll
     for (int c = 0; c < NT; ++c) finite = finite && (fabs(dxv[c]) < INFINITY);
-    if (g == 0) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) { dxs[32 * h + 2 * j] = dxv[2 * h]; dxs[32 * h + 2 * j + 1] = dxv[2 * h + 1]; }
-    }
+    if (g == 0) stv<NT, QPL>(dxs, j, dxv);
     lds_fence();
     double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
     if (lane < m) {
@@ -631,13 +676,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const double nanv = __builtin_nan("");
     double* dp = (double*)a.delta + p * a.delta_stride;
     if (g == 0) {
+      double outv[NT];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        d2 o;
-        o[0] = st == MO_STATUS_OK ? dxv[2 * h] : nanv;
-        o[1] = st == MO_STATUS_OK ? dxv[2 * h + 1] : nanv;
-        *(d2*)(dp + 32 * h + 2 * j) = o;
-      }
+      for (int c = 0; c < NT; ++c) outv[c] = st == MO_STATUS_OK ? dxv[c] : nanv;
+      stv<NT, QPL>(dp, j, outv);
       if (j < k) dp[N + m + j] = st == MO_STATUS_OK ? dyv : nanv;
     }
     if (lane < m) {
@@ -692,10 +734,10 @@ template <int NT, int WPS> struct SolveCfg {
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
 
-template <int NT, int WPS, int SW>
+template <int NT, int WPS, int SW, bool QPL>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
   using C = SolveCfg<NT, WPS>;
-  constexpr int N = C::N, NB = NT + 1, NH = C::NH, SLOT = C::SLOT, D = C::D;
+  constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
 
   __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
@@ -743,10 +785,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4, j = lane & 15;
 
-    const double* Jp = (const double*)a.J + p * a.J_stride;
-    const double* rg = (const double*)a.r + p * a.r_stride;
+    const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
+    const double* rg = QPL ? nullptr : (const double*)a.r + p * a.r_stride;
     double* vp = (double*)a.vars + p * a.vars_stride;
-    const double lam = a.lambda > 0.0 ? a.lambda : 0.0;
+    const double lam = (!QPL && a.lambda > 0.0) ? a.lambda : 0.0;  // a given G already carries the LM damping
 
     // ---- constants of the problem
     int cvar = 0; double ca = 1.0, cb = 0.0;
@@ -765,8 +807,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     for (int c = 0; c < NT; ++c) xv[c] = 0.0;
     const bool iterate_mode = a.mode == MODE_ITERATE;  // one Iterate (qp.cc:153-201) on the caller's state and mu
     if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
-#pragma unroll
-      for (int h = 0; h < NH; ++h) { const d2 v = *(const d2*)(vp + 32 * h + 2 * j); xv[2 * h] = v[0]; xv[2 * h + 1] = v[1]; }
+      ldv<NT, QPL>(vp, j, xv);
       if (j < k) yv = vp[N + m + j];
       if (lane < m) { cs = vp[N + lane]; cz = vp[N + m + k + lane]; }
     }
@@ -781,10 +822,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
     // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
     auto clamp_and_init_slacks = [&]() {
-      if (g == 0) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) { xs[32 * h + 2 * j] = xv[2 * h]; xs[32 * h + 2 * j + 1] = xv[2 * h + 1]; }
-      }
+      if (g == 0) stv<NT, QPL>(xs, j, xv);
       lds_fence();
       for (int c = 0; c < m; ++c) {  // wave-uniform loop; one constraint at a time keeps the reference's order
         if (lane == c) {
@@ -796,8 +834,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
         lds_fence();
       }
-#pragma unroll
-      for (int h = 0; h < NH; ++h) { const d2 v = *(const d2*)(&xs[32 * h + 2 * j]); xv[2 * h] = v[0]; xv[2 * h + 1] = v[1]; }
+      ldv<NT, QPL>(xs, j, xv);
       if (lane < m) {
         const double sv = ca * xs[cvar] + cb;
         cs = sv > 1.0e-9 ? sv : 1.0e-9;
@@ -830,26 +867,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       int lane_q = threadIdx.x & 63;
       asm volatile("" : "+v"(lane_q));
       const int lane = lane_q, g = lane_q >> 4, j = lane_q & 15;  // shadow the per-problem copies inside the pass
-      const double* Al = Ap + j + (size_t)(2 * g) * a.A_ld;
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       JStream<NT, D> stream;
-      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
-      stream.prologue();
+      if (!QPL) {
+        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
+        stream.prologue();
+      }
       d4 U[NB * NB];
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int col_u = 32 * (c >> 1) + 8 * t + (c & 1);
-          U[c * NB + NT][t] = (j < k) ? Al[(size_t)col_u * a.A_ld] : 0.0;
-        }
-      }
+      load_a_tiles<NT, QPL>(Ap, a.A_ld, k, g, j, U);
       // publish the state for the layout conversions below; zero the per-variable scatter arrays
       if (g == 0) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) { xs[32 * h + 2 * j] = xv[2 * h]; xs[32 * h + 2 * j + 1] = xv[2 * h + 1]; }
+        stv<NT, QPL>(xs, j, xv);
 #pragma unroll
         for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
         ysm[j] = (j < k) ? yv : 0.0;
@@ -859,18 +889,22 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
         rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0;
       }
-      double cpart[NT];
-#pragma unroll
-      for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
-      stream.run(U, cpart);
-#pragma unroll
-      for (int c = 0; c < NT; ++c) {  // G = J^T J + lambda I (nonlinear.cc:187-189): lambda is part of G in the residual too
-#pragma unroll
-        for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? lam : 0.0;
-      }
       double cvec[NT];
+      if (QPL) {
+        load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, g, j, U, cvec);
+      } else {
+        double cpart[NT];
 #pragma unroll
-      for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+        for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
+        stream.run(U, cpart);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {  // G = J^T J + lambda I (nonlinear.cc:187-189): lambda is part of G in the residual too
+#pragma unroll
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? lam : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+      }
       lds_fence();
       double r_pi = 0.0, r_comp = 0.0;
       if (include_ineq && lane < m) {
@@ -907,11 +941,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       lds_fence();
       double r_d[NT];
+      {
+        double azv[NT];
+        ldv<NT, QPL>(azS, j, azv);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const d2 az = *(const d2*)(&azS[32 * h + 2 * j]);
-        r_d[2 * h] = cross_row_sum(acc1[2 * h]) + tmp[16 * (2 * h) + j] + cvec[2 * h] - az[0];          // qp.cc:404-406, 415
-        r_d[2 * h + 1] = cross_row_sum(acc1[2 * h + 1]) + tmp[16 * (2 * h + 1) + j] + cvec[2 * h + 1] - az[1];
+        for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
       }
       const double r_pe = (j < k) ? cross_row_sum(acc1[NT]) + b_col : 0.0;                                 // qp.cc:408
       {
@@ -969,16 +1003,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       lds_fence();
+      {
+        double dd[NT], rr[NT];
+        ldv<NT, QPL>(diagS, j, dd);
+        ldv<NT, QPL>(rhoS, j, rr);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const d2 dd = *(const d2*)(&diagS[32 * h + 2 * j]);
-        const d2 rr = *(const d2*)(&rhoS[32 * h + 2 * j]);
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int c = 2 * h + e;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? dd[e] : 0.0;
-          if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[e]);          // -r_aug, permuted order (qp.cc:337-342)
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? dd[c] : 0.0;
+          if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[c]);          // -r_aug, position order (qp.cc:337-342)
         }
       }
       if (g == 0) ysm[16 + j] = -r_pe;
@@ -1016,8 +1049,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         continue;
       }
       if (g == 0) {
+        double dxn[NT];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) { tmp[32 * h + 2 * j] = xb[2 * h]; tmp[32 * h + 2 * j + 1] = xb[2 * h + 1]; }
+        for (int c = 0; c < NT; ++c) dxn[c] = xb[c];
+        stv<NT, QPL>(tmp, j, dxn);  // dx, natural order
       }
       lds_fence();
       double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
@@ -1042,7 +1077,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
         if (a.delta) {
           double* dp = (double*)a.delta + p * a.delta_stride;
-          if (lane < N / 2) { dp[2 * lane] = tmp[2 * lane]; dp[2 * lane + 1] = tmp[2 * lane + 1]; }  // dx, natural order
+          if (lane < N) dp[lane] = tmp[lane];  // dx, natural order
           if (lane < m) { dp[N + lane] = dsv; dp[N + m + k + lane] = dzv; }
           if (g == 0 && j < k) dp[N + m + j] = dyv;
         }
@@ -1057,8 +1092,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
     // ---- outputs: state, termination, iteration count, Lagrange summary, status
     if (g == 0) {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) { d2 o; o[0] = xv[2 * h]; o[1] = xv[2 * h + 1]; *(d2*)(vp + 32 * h + 2 * j) = o; }
+      stv<NT, QPL>(vp, j, xv);
       if (j < k) vp[N + m + j] = yv;
     }
     if (lane < m) { vp[N + lane] = cs; vp[N + m + k + lane] = cz; }
@@ -1097,17 +1131,26 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   }
   if (a.n != 32 && a.n != 64) return false;
   if (a.k > 14 || a.m > 64 || a.m < 0) return false;
-  if (!a.J || !a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
-  if (!aligned16(a.J) || (a.J_stride & 1)) return false;
-  if (!aligned16(a.r) || (a.r_stride & 1)) return false;  // r rides in the ring as 16-byte pieces
-  if (!aligned16(a.vars) || (a.vars_stride & 1)) return false;
-  if (a.mode == MODE_STEP && (!a.delta || !aligned16(a.delta) || (a.delta_stride & 1))) return false;
-  if (!a.ticket) return false;
+  if (!a.ticket || !a.vars) return false;
+  if (a.mode == MODE_STEP && !a.delta) return false;
+  if (a.J) {  // J-level: 16-byte pieces of J, r and of the state / direction vectors
+    if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
+    if (!aligned16(a.J) || (a.J_stride & 1)) return false;
+    if (!aligned16(a.r) || (a.r_stride & 1)) return false;
+    if (!aligned16(a.vars) || (a.vars_stride & 1)) return false;
+    if (a.delta && (!aligned16(a.delta) || (a.delta_stride & 1))) return false;
+  } else {    // QP-level: G, c given; no alignment requirements
+    if (!a.G || !a.c || a.G_ld < a.n) return false;
+  }
   return true;
 }
 
 const char* fused_name(const KernelArgs& a, int) {
-  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) return a.n == 64 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
+  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {
+    if (!a.J) return a.n == 64 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
+    return a.n == 64 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
+  }
+  if (!a.J) return a.n == 64 ? "fused_qp_f64_n64" : "fused_qp_f64_n32";
   return a.n == 64 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
 }
 
@@ -1130,12 +1173,27 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     if (sgrid > need) sgrid = need;
     if (sgrid < 1) sgrid = 1;
     const dim3 sgd((unsigned)sgrid), sbd(256 * swps);
-    if (a.n == 64) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3>), sgd, sbd, 0, stream, a);
-    else hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3>), sgd, sbd, 0, stream, a);
+    if (a.n == 64) {
+      if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false>), sgd, sbd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, true>), sgd, sbd, 0, stream, a);
+    } else {
+      if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, false>), sgd, sbd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, true>), sgd, sbd, 0, stream, a);
+    }
     return hipGetLastError();
   }
   const dim3 gd((unsigned)grid), bd(256 * wps);
-#define MO_FUSED_LAUNCH(NT_, WPS_, SW_) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, SW_>), gd, bd, 0, stream, a)
+  if (!a.J) {  // QP-level input: default flavour only
+    if (a.n == 64) {
+      if (wps == 3) hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, true>), gd, bd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 2, 3, true>), gd, bd, 0, stream, a);
+    } else {
+      if (wps == 3) hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, true>), gd, bd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 4, 3, true>), gd, bd, 0, stream, a);
+    }
+    return hipGetLastError();
+  }
+#define MO_FUSED_LAUNCH(NT_, WPS_, SW_) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, SW_, false>), gd, bd, 0, stream, a)
 #define MO_FUSED_BY_SW(NT_, WPS_)                     \
   do {                                                \
     if (sw == 0) MO_FUSED_LAUNCH(NT_, WPS_, 0);       \

@@ -464,3 +464,38 @@ def test_fused_status_words_and_shared_constraints():
                                               cons_var=rep(cv), cons_a=rep(ca), cons_b=rep(cb), vars_=vars2, mu=hb2.mu)
     assert torch.all(status2 == 0) and np.all(rs2 == 0)
     assert rel_inf_rows(delta2.cpu().numpy(), ref2).max() < 1e-10
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_fused_qp_level_step_and_solve(cfg):
+    """QP-level input (G lower-triangular column-major, c: the reference's own mini_opt::QP) on the fused kernels: Newton step,
+    Iterate and the full Solve against the oracle, problem by problem.  Uses an odd state stride on purpose (no alignment needs)."""
+    d = synth.CONFIGS[cfg]
+    B = 17
+    hb = synth.make_batch(d["n"], d["k"], d["m"] - 1, d["m_r"], B, stream=31) if False else synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], B, stream=31)
+    n, k, m = hb.n, hb.k, hb.m
+    G = np.einsum("bqi,bqj->bij", hb.J, hb.J) + hb.lam * np.eye(n)
+    c = np.einsum("bqi,bq->bi", hb.J, hb.r)
+    Gl = np.tril(G)                                   # only the lower triangle is valid, like Eigen's triangularView<Lower>
+    Gl_bad_upper = Gl + np.triu(np.full((n, n), 123.0), 1)   # garbage above the diagonal must be ignored (qp.cc:289, :404)
+    prob = Q.BatchedQP(n=n, k=k, m=m, G=T(Gl_bad_upper.transpose(0, 2, 1)), c=T(c), A_eq=T(hb.A_eq), b_eq=T(hb.b_eq),
+                       cons_var=T(hb.cons_var, torch.int32), cons_a=T(hb.cons_a), cons_b=T(hb.cons_b))
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused_qp"), s.step_kernel()
+    s.SetVariables(T(hb.vars))
+    delta, alpha, status = s.NewtonStep(T(hb.mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, G=Gl.transpose(0, 2, 1), c=c, A_eq=hb.A_eq, b_eq=hb.b_eq,
+                                                            cons_var=hb.cons_var, cons_a=hb.cons_a, cons_b=hb.cons_b, vars_=hb.vars, mu=hb.mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < TOL64
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-10, max_iterations=14, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED)
+    out = s.Solve(Q.Params(**kw))
+    assert torch.all(out.status == 0)
+    v = s.variables().cpu().numpy()
+    for p in range(B):
+        o = orc.Solver(orc.QP(G=Gl[p], c=c[p], A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=hb.cons_var[p], cons_a=hb.cons_a[p],
+                              cons_b=hb.cons_b[p]))
+        term, its = o.solve(**kw)
+        assert int(out.termination_state[p]) == term and int(out.num_iterations[p]) == len(its)
+        np.testing.assert_allclose(v[p], o.variables, rtol=1e-7, atol=1e-9)
