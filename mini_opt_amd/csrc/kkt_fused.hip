@@ -722,13 +722,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 // [G x + c - A^T y - A_i^T z ; A x + b] as a tile product K [x; -y] in registers (qp.cc:404-419), and -- unlike the
 // one-shot step kernel -- solves for the DIRECTION with the residual as right-hand side, exactly the reference's system
 // (qp.cc:255-268, 337-363), so the loop keeps Newton's self-correcting behaviour down to tight KKT tolerances.
-// BarrierStrategy COMPLEMENTARITY and FIXED_DECREASE; PREDICTOR_CORRECTOR runs on the generic kernel.
+// All three BarrierStrategy values; PREDICTOR_CORRECTOR costs two passes (two factorisations) per iteration.
 template <int NT, int WPS> struct SolveCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;
   static constexpr int SLOT = NH * 1024 + 64;
   static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 6) : 8;
-  static constexpr int VEC = (6 * N + 32) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32]
+  static constexpr int VEC = (6 * N + 32 + 128) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32], affine ds / dz [2][64]
   static constexpr int LDS = D * SLOT + VEC;
 };
 
@@ -750,6 +750,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   double* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
   double* const tmp = rhoS + N;                                   // layout-conversion scratch (R <-> V16, natural <-> permuted)
   double* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
+  double* const affS = ysm + 32;                                  // predictor-corrector: ds_aff [0,64), dz_aff [64,128)
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
   const int k = a.k, m = a.m, m_r = a.m_r;
@@ -859,6 +860,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     };
     double mu_used = mu;   // the mu handed to the previous Iterate
     double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
+    // Mehrotra predictor-corrector (qp.cc:170-187): the predictor pass solves with mu = 0 and probes alpha(tau = 1); the
+    // corrector pass rebuilds and re-factors the same tiles (the elimination consumes them) with the second-order term
+    // ds_aff dz_aff and mu = sigma mu_input on the right-hand side.
+    const bool use_pc = (iterate_mode ? a.barrier_strategy : sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
+    bool corrector_pass = false;
+    double ip_mu = mu, probe_p = __builtin_nan(""), probe_d = __builtin_nan(""), mu_aff = __builtin_nan(""), mu_pc = 0.0;
 
     while (st == MO_STATUS_OK) {
       const bool include_ineq = !guess_pass;
@@ -959,7 +966,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         n_rpi2 = wave_sum_f64(r_pi * r_pi);
         n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
       }
-      if (!guess_pass && !iterate_mode) {
+      if (!guess_pass && !iterate_mode && !corrector_pass) {
         // ---- the decision point of Solve (qp.cc:116-147)
         if (it > 0) {
           double kf[4];
@@ -968,8 +975,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           if (iter_out && lane == 0) {
             double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
             rec[4] = kf[0]; rec[5] = kf[1]; rec[6] = kf[2]; rec[7] = kf[3];
-            rec[8] = mu_used; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
-            rec[11] = __builtin_nan(""); rec[12] = __builtin_nan(""); rec[13] = __builtin_nan("");
+            rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
+            rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
           }
           double kmax = kf[0];
           kmax = kf[1] > kmax ? kf[1] : kmax; kmax = kf[2] > kmax ? kf[2] : kmax; kmax = kf[3] > kmax ? kf[3] : kmax;
@@ -991,7 +998,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
-      const double mu_step = m > 0 ? mu : 0.0;                        // qp.cc:165-169
+      const bool predictor_pass = use_pc && !guess_pass && !corrector_pass;
+      const double mu_step = m > 0 ? (predictor_pass ? 0.0 : (corrector_pass ? mu_pc : mu)) : 0.0;  // qp.cc:165-187
+      const double aff = (corrector_pass && lane < m) ? affS[lane] * affS[64 + lane] : 0.0;       // ds_aff dz_aff, qp.cc:341
       double cs_inv = 1.0;
       if (include_ineq) {
         if (__any((lane < m) && !(cs > 0.0))) { st = MO_STATUS_NONPOSITIVE_SLACK; break; }  // qp.cc:285
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         if (lane < m) {
           const double zs = cz * cs_inv;
           atomicAdd(&diagS[cvar], ca * zs * ca);                                          // qp.cc:296
-          atomicAdd(&rhoS[cvar], ca * zs * r_pi + ca * (r_comp - mu_step) * cs_inv);      // qp.cc:340-341
+          atomicAdd(&rhoS[cvar], ca * zs * r_pi + ca * (r_comp + aff - mu_step) * cs_inv);  // qp.cc:340-341
         }
       }
       lds_fence();
@@ -1058,14 +1067,33 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
       if (lane < m) {
         dsv = ca * tmp[cvar] + r_pi;                                                   // qp.cc:361
-        dzv = -(cz * cs_inv) * dsv - cs_inv * (r_comp - mu_step);                      // qp.cc:362
-        if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -0.995 * cs * rcp_f64(dsv);       // qp.cc:192, 498-503
-        if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -0.995 * cz * rcp_f64(dzv);
+        dzv = -(cz * cs_inv) * dsv - cs_inv * (r_comp + aff - mu_step);                // qp.cc:362
+        const double tau = predictor_pass ? 1.0 : 0.995;                               // qp.cc:174, 192
+        if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -tau * cs * rcp_f64(dsv);         // qp.cc:498-503
+        if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -tau * cz * rcp_f64(dzv);
         finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
       }
       if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
       ap = cross_row_min(row_min(ap));
       ad = cross_row_min(row_min(ad));
+      if (predictor_pass) {
+        probe_p = ap; probe_d = ad;                                                    // alpha_probe, qp.cc:174
+        if (lane < m) { affS[lane] = dsv; affS[64 + lane] = dzv; }                     // delta_affine_, qp.cc:177
+        const double sdz = wave_sum_f64(lane < m ? cs * dzv : 0.0), zds = wave_sum_f64(lane < m ? cz * dsv : 0.0),
+                     dsdz = wave_sum_f64(lane < m ? dsv * dzv : 0.0);
+        double ma = mu;                                                                // qp.cc:519-537
+        ma += ad * sdz / (double)m;
+        ma += ap * zds / (double)m;
+        ma += (ad * ap) * dsdz / (double)m;
+        mu_aff = ma > 0.0 ? ma : 0.0;
+        const double ratio = mu_aff / mu;
+        mu_pc = (ratio * ratio * ratio) * mu;                                          // qp.cc:182-183
+        corrector_pass = true;
+        lds_fence();
+        continue;
+      }
+      ip_mu = corrector_pass ? mu_pc : mu;                                             // IPIterationOutputs::mu
+      corrector_pass = false;
       // x,s += alpha_p (dx,ds) ; y,z += alpha_d (dy,dz), qp.cc:196-199
 #pragma unroll
       for (int c = 0; c < NT; ++c) xv[c] = fma(xb[c], ap, xv[c]);
@@ -1083,8 +1111,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
         if (a.ip_out && lane == 0) {
           double* ip = (double*)a.ip_out + p * MO_IP_RECORD;
-          ip[0] = mu; ip[1] = ap; ip[2] = ad;  // outputs.mu = mu_input, qp.cc:160
-          ip[3] = __builtin_nan(""); ip[4] = __builtin_nan(""); ip[5] = __builtin_nan("");
+          ip[0] = ip_mu; ip[1] = ap; ip[2] = ad;  // outputs.mu = mu_input (sigma mu_input after a corrector), qp.cc:160, 183
+          ip[3] = probe_p; ip[4] = probe_d; ip[5] = mu_aff;
         }
         break;
       }
@@ -1122,13 +1150,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64 || a.flags != 0) return false;
-  if (a.mode == MODE_SOLVE) {
-    if (a.sp.barrier_strategy == MO_PREDICTOR_CORRECTOR) return false;
-  } else if (a.mode == MODE_ITERATE) {
-    if (a.barrier_strategy == MO_PREDICTOR_CORRECTOR) return false;
-  } else if (a.mode != MODE_STEP) {
-    return false;
-  }
+  if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
   if (a.n != 32 && a.n != 64) return false;
   if (a.k > 14 || a.m > 64 || a.m < 0) return false;
   if (!a.ticket || !a.vars) return false;

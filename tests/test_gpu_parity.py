@@ -345,7 +345,7 @@ def test_fused_kernel_is_selected_for_headline_configs():
 # ------------------------------------------------------------------ fused on-device Solve (row f1) vs the oracle's Solve
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
 @pytest.mark.parametrize("guess", [Q.NAIVE, Q.SOLVE_EQUALITY_CONSTRAINED, Q.USER_PROVIDED])
-@pytest.mark.parametrize("strategy", [Q.COMPLEMENTARITY, Q.FIXED_DECREASE])
+@pytest.mark.parametrize("strategy", [Q.COMPLEMENTARITY, Q.FIXED_DECREASE, Q.PREDICTOR_CORRECTOR])
 def test_fused_solve_vs_oracle(cfg, guess, strategy):
     """mo_qp_solve on J-level input runs the fused Solve kernel: same termination, iteration count, optimum and per-iteration
     KKT records as the oracle's restatement of QPInteriorPointSolver::Solve (qp.cc:100-151), problem by problem; the generic
@@ -378,8 +378,9 @@ def test_fused_solve_vs_oracle(cfg, guess, strategy):
             for i, itr in enumerate(its):
                 exp = [itr.kkt_initial.r_dual, itr.kkt_initial.r_comp, itr.kkt_initial.r_primal_eq, itr.kkt_initial.r_primal_ineq,
                        itr.kkt_final.r_dual, itr.kkt_final.r_comp, itr.kkt_final.r_primal_eq, itr.kkt_final.r_primal_ineq,
-                       itr.ip.mu, itr.ip.alpha_primal, itr.ip.alpha_dual]
-                np.testing.assert_allclose(rec[p][i][:11], exp, rtol=1e-6, atol=1e-9 + 1e-12 * scale)
+                       itr.ip.mu, itr.ip.alpha_primal, itr.ip.alpha_dual,
+                       itr.ip.alpha_probe_primal, itr.ip.alpha_probe_dual, itr.ip.mu_affine]
+                np.testing.assert_allclose(rec[p][i], exp, rtol=1e-6, atol=1e-9 + 1e-12 * scale, equal_nan=True)
             y = o.blocks(o.variables)[2]
             np.testing.assert_allclose(lag[p], [y.min(), np.abs(y).max()], rtol=1e-7, atol=1e-9)
 

@@ -35,17 +35,19 @@ def main():
             s.SetVariables(vars_)
             t = timeit(lambda: s.NewtonStep(mu, 0.995), 5)
             out[("generic" if force else s.step_kernel()) + "_step_per_s"] = batch / t
-        s = Q.QPInteriorPointSolver(prob)
-        params = Q.Params(initial_mu=1.0, sigma=0.1, max_iterations=10, termination_kkt_tol=1e-8 if dt == torch.float64 else 1e-3)
-        res = {}
-        def run():
-            res["o"] = s.Solve(params)
-        t = timeit(run, 2)
-        o = res["o"]
-        out["solve_per_s"] = batch / t
-        out["solve_mean_iterations"] = float(o.num_iterations.double().mean())
-        out["solve_satisfied_frac"] = float((o.termination_state == 0).double().mean())
-        out["solve_status_ok_frac"] = float((o.status == 0).double().mean())
+        for sname, strat in (("", Q.COMPLEMENTARITY), ("_pc", Q.PREDICTOR_CORRECTOR)):
+            s = Q.QPInteriorPointSolver(prob)
+            params = Q.Params(initial_mu=1.0, sigma=0.1, max_iterations=10, barrier_strategy=strat,
+                              termination_kkt_tol=1e-8 if dt == torch.float64 else 1e-3)
+            res = {}
+            def run():
+                res["o"] = s.Solve(params)
+            t = timeit(run, 2)
+            o = res["o"]
+            out["solve%s_per_s" % sname] = batch / t
+            out["solve%s_mean_iterations" % sname] = float(o.num_iterations.double().mean())
+            out["solve%s_satisfied_frac" % sname] = float((o.termination_state == 0).double().mean())
+            out["solve%s_status_ok_frac" % sname] = float((o.status == 0).double().mean())
         print(json.dumps(out), flush=True)
 
 
