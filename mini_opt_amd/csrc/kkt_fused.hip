@@ -198,6 +198,14 @@ __device__ inline void load_g_tiles(const double* G, int ld, const double* cg, i
   }
 }
 
+// Lane index recomputed on the spot (two VALU ops).  The asm is volatile on purpose: nothing derived from it can be hoisted
+// out of a loop and kept live in VGPRs the tiles need.
+__device__ inline int lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // LDS-DMA: every lane's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * lane (no VGPR destination).
 // hipcc does not count this load: its completion is waited for by hand with wait_vmcnt<N>() (loads retire in order).
 __device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
@@ -207,6 +215,21 @@ __device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
+}
+// Same with 4 bytes per lane: LDS byte address lds_dst + 4 * lane.  64 lanes move 32 consecutive doubles.
+__device__ inline void dma4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+// `count` consecutive doubles (count <= 64, wave-uniform) from global memory to LDS without touching a VGPR destination.
+__device__ inline void dma_doubles(const double* src, unsigned lds_dst, int count, int lane) {
+  const char* s4 = reinterpret_cast<const char*>(src) + 4 * lane;
+  if (lane < 2 * count) dma4(s4, lds_dst);
+  if (lane + 64 < 2 * count) dma4(s4 + 256, lds_dst + 256);
 }
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // single-wave workgroup
@@ -264,7 +287,7 @@ __device__ inline void masked_zero4(d4& T, unsigned long long mask) {  // T[0..3
 template <int K>
 __device__ inline void sweep_step_lean(d4& T, bool& ok, int g, int j) {
   constexpr int src_g = K & 3, src_t = K >> 2;
-  const unsigned long long mcol = __builtin_amdgcn_ballot_w64(j == K);      // the four lanes of tile column k
+  constexpr unsigned long long mcol = 0x0001000100010001ull << K;           // the four lanes of tile column k (j == K)
   const unsigned long long mrow = 0xFFFFull << (16 * src_g);                // the 16 lanes of the row group that holds row k
   const double rowreg = T[src_t];  // every broadcast below is taken before any register of T is modified
   const double d = readlane_f64(rowreg, 16 * src_g + K);
@@ -442,8 +465,8 @@ template <int NT, int WPS> struct FusedCfg {
   static constexpr int NH = NT / 2;                 // 16-byte J loads per lane per 4-row group
   static constexpr int DPS = NH + 1;                // LDS-DMA instructions per 4-row group (J pieces + 32 B of r)
   static constexpr int SLOT = NH * 1024 + 64;       // ring slot: 4 rows of J (lane-linear) + r[4s..4s+3]
-  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 8) : 8;  // ring depth (4-row groups in flight per wave), LDS-limited
-  static constexpr int VEC = 5 * N * 8;             // xs, diagS, rhsS, rp, dxs
+  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 7) : (WPS >= 4 ? 4 : 8);  // ring depth (4-row groups in flight per wave), LDS-limited
+  static constexpr int VEC = (3 * N + 4 * 64 + 32 + 32) * 8;  // xs, diagS|rp, rhsS|dxs, cons a/b/s/z [64], cons var [64 int], y[16], b_eq[16]
   static constexpr int LDS = D * SLOT + VEC;
 };
 
@@ -462,9 +485,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   double* const xs = reinterpret_cast<double*>(smem + D * SLOT);  // x, natural order
   double* const diagS = xs + N;                                   // barrier diagonal per variable, natural order
   double* const rhsS = diagS + N;                                 // inequality part of the rhs per variable, natural order
-  double* const rp = rhsS + N;                                    // right-hand side, permuted order
-  double* const dxs = rp + N;                                     // dx, natural order
+  double* const rp = diagS;                                       // right-hand side, permuted order (diagS is dead by then)
+  double* const dxs = rhsS;                                       // dx, natural order (rhsS is dead by then)
+  double* const cA = rhsS + N;                                    // per-constraint a, b, s, z and variable index; y; b_eq:
+  double* const cB = cA + 64;                                     //   LDS-DMA targets of P0 (the small per-problem vectors
+  double* const cS = cB + 64;                                     //   cost no VGPRs while J streams)
+  double* const cZ = cS + 64;
+  int* const cV = reinterpret_cast<int*>(cZ + 64);
+  double* const yb = cZ + 64 + 32;
+  double* const bb = yb + 16;
   const unsigned ring_base = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (low 32 bits of the flat address)
+  const unsigned vec_base = ring_base + D * SLOT;                 // LDS byte address of xs
 
   const int k = a.k, m = a.m, m_r = a.m_r;
 #ifdef MO_FUSED_STAMPS
@@ -478,14 +509,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   // idle at the end (measured with tools/phase_timer).  Tickets are taken in guided chunks (up to 8 problems while the
   // queue is long, single problems at the end) because one counter word sustains only ~88 M atomics/s, and the next
   // chunk is requested at the START of the current chunk's last problem, so the atomic's latency hides under the J stream.
-  const long long total_waves = (long long)gridDim.x * WAVES;
+  const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);  // ~ remaining / (4 waves' worth)
   auto chunk_for = [&](long long observed) -> int {
-    const long long c = (a.batch - observed) / (4 * total_waves);
+    const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
   auto take_ticket = [&](int chunk) -> unsigned long long {
     unsigned long long t = 0;
-    if ((threadIdx.x & 63) == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    if (lane_id() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
   };
   auto uniform64 = [](unsigned long long v) -> long long {
@@ -507,8 +538,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     // Lane coordinates are made opaque once per problem so that nothing derived from them (gather addresses, masks,
     // bpermute addresses) is hoisted out of the problem loop and kept live for the whole kernel: the tile registers
     // need the room.
-    int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
+    const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
 
     const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
@@ -523,33 +553,25 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       stream.prologue();
     }
 
-    // ---- P0: every small global load of this problem is issued here (behind the ring fill), so that it retires under P1
+    // ---- P0: every small vector of this problem goes global -> LDS by DMA, issued behind the ring fill; nothing of it sits in
+    //          a VGPR while J streams (the tile registers need the room), and the last wait of the stream covers it.
     d4 U[NB * NB];
 #pragma unroll
     for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-    d2 xv0 = d2{0.0, 0.0};  // x[2 lane], x[2 lane + 1] (QPL: x[lane]); parked in registers until the J stream is done
-    if (QPL) { if (lane < N) xv0[0] = vp[lane]; }
-    else if (lane < N / 2) xv0 = *(const d2*)(vp + 2 * lane);
-    int cvar = 0; double ca = 1.0, cb = 0.0, cs = 1.0, cz = 0.0;
-    bool bad_index = false;
-    if (lane < m) {
-      cvar = a.cons_var[p * a.cons_stride + lane];
-      ca = ((const double*)a.cons_a)[p * a.cons_stride + lane];
-      cb = ((const double*)a.cons_b)[p * a.cons_stride + lane];
-      cs = vp[N + lane];
-      cz = vp[N + m + k + lane];
+    dma_doubles(vp, vec_base, N, lane);                                                     // x -> xs
+    if (m > 0) {
+      if (lane < m) dma4(a.cons_var + p * a.cons_stride + lane, vec_base + (3 * N + 256) * 8);
+      dma_doubles((const double*)a.cons_a + p * a.cons_stride, vec_base + (3 * N) * 8, m, lane);
+      dma_doubles((const double*)a.cons_b + p * a.cons_stride, vec_base + (3 * N + 64) * 8, m, lane);
+      dma_doubles(vp + N, vec_base + (3 * N + 128) * 8, m, lane);                            // s
+      dma_doubles(vp + N + m + k, vec_base + (3 * N + 192) * 8, m, lane);                    // z
     }
-    const double yv = (j < k) ? vp[N + m + j] : 0.0;
+    if (k > 0) {
+      dma_doubles(vp + N + m, vec_base + (3 * N + 288) * 8, k, lane);                        // y
+      dma_doubles((const double*)a.b + p * a.b_stride, vec_base + (3 * N + 304) * 8, k, lane);  // b_eq
+    }
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
     load_a_tiles<NT, QPL>(k > 0 ? (const double*)a.A + p * a.A_stride : nullptr, a.A_ld, k, g, j, U);
-    // b_eq: raw loads only (any arithmetic on a loaded value here would make hipcc wait for it before the J stream starts)
-    double b_row[4], b_col = 0.0;
-    {
-      const double* bp = k > 0 ? (const double*)a.b + p * a.b_stride : nullptr;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) b_row[t] = (g + 4 * t < k) ? bp[g + 4 * t] : 0.0;
-      b_col = (j < k) ? bp[j] : 0.0;
-    }
 
     MO_STAMP(0);
     // ---- P1: stream J once through the LDS-DMA ring; G = J^T J on the matrix cores (upper block triangle of tiles),
@@ -569,15 +591,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     MO_STAMP(1);
 
     // ---- P3: per-constraint barrier terms, scattered per variable through LDS (duplicates on one variable accumulate)
-    if (QPL) {
-      if (lane < N) { xs[lane] = xv0[0]; diagS[lane] = 0.0; rhsS[lane] = 0.0; }
-    } else if (lane < N / 2) {
-      xs[2 * lane] = xv0[0]; xs[2 * lane + 1] = xv0[1];
+    wait_vmcnt<0>();  // the P0 DMAs have landed (they are older than the last ring DMA the stream waited for)
+    if (lane < N / 2) {
       diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
       rhsS[2 * lane] = 0.0; rhsS[2 * lane + 1] = 0.0;
     }
-    lds_fence();  // xs / diagS / rhsS initialised
-    bad_index = (lane < m) && ((cvar < 0) || (cvar >= N));           // first use of a P0 load: after the J stream
+    int cvar = 0; double ca = 1.0, cb = 0.0, cs = 1.0, cz = 0.0;
+    if (lane < m) { cvar = cV[lane]; ca = cA[lane]; cb = cB[lane]; cs = cS[lane]; cz = cZ[lane]; }
+    lds_fence();  // diagS / rhsS initialised
+    bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= N));
     if (bad_index) cvar = 0;
     const bool slack_bad = __any((lane < m) && !(cs > 0.0));
     const bool any_bad_index = __any(bad_index);
@@ -601,8 +623,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #pragma unroll
     for (int t = 0; t < 4; ++t) {  // y diagonal tile = [0, -b_eq; -b_eq^T, 0]: (r, kRC) = -b[r], (kRC, q) = -b[q]
       double v = 0.0;
-      if (j == kRC) v = -b_row[t];            // b_row is 0 for r >= k
-      if (g + 4 * t == kRC) v = -b_col;       // b_col is 0 for j >= k
+      if (j == kRC) v = (g + 4 * t < k) ? -bb[g + 4 * t] : 0.0;
+      if (g + 4 * t == kRC) v = (j < k) ? -bb[j] : 0.0;
       U[NT * NB + NT][t] = v;
     }
     const double lam = (!QPL && a.lambda > 0.0) ? a.lambda : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
@@ -656,6 +678,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     lds_fence();
     double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
     if (lane < m) {
+      const double ca = cA[lane], cb = cB[lane], cs = cS[lane], cz = cZ[lane];     // re-read: not kept live across P5
+      const int cvar = bad_index ? 0 : cV[lane];
       const double r_pi = ca * xs[cvar] + cb - cs;                                  // qp.cc:416
       dsv = ca * dxs[cvar] + r_pi;                                                  // qp.cc:361
       dzv = -(cz * cs_inv) * dsv - cs_inv * (cs * cz - mu);                         // qp.cc:362
@@ -666,7 +690,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     }
     ap = cross_row_min(row_min(ap));
     ad = cross_row_min(row_min(ad));
-    const double dyv = (j < k) ? (-xb[NT] - yv) : 0.0;                              // y+ - y
+    const double dyv = (j < k) ? (-xb[NT] - yb[j]) : 0.0;                           // y+ - y
     finite = finite && (fabs(dyv) < INFINITY);
     int st = MO_STATUS_OK;
     if (!__all(finite)) st = MO_STATUS_NONFINITE;
@@ -756,14 +780,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   const int k = a.k, m = a.m, m_r = a.m_r;
   const mo_solve_params& sp = a.sp;
 
-  const long long total_waves = (long long)gridDim.x * WAVES;
+  const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);  // ~ remaining / (4 waves' worth)
   auto chunk_for = [&](long long observed) -> int {
-    const long long c = (a.batch - observed) / (4 * total_waves);
+    const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
   auto take_ticket = [&](int chunk) -> unsigned long long {
     unsigned long long t = 0;
-    if ((threadIdx.x & 63) == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    if (lane_id() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
   };
   auto uniform64 = [](unsigned long long v) -> long long {
@@ -782,8 +806,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       next_chunk = chunk_for(p);
       next_ticket = take_ticket(next_chunk);
     }
-    int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
+    const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
 
     const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
@@ -871,9 +894,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       const bool include_ineq = !guess_pass;
       // lane coordinates are re-made opaque every pass: nothing derived from them may be hoisted out of the pass loop and
       // kept in VGPRs across the factorisation (see the step kernel)
-      int lane_q = threadIdx.x & 63;
-      asm volatile("" : "+v"(lane_q));
-      const int lane = lane_q, g = lane_q >> 4, j = lane_q & 15;  // shadow the per-problem copies inside the pass
+      const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       JStream<NT, D> stream;
       if (!QPL) {
