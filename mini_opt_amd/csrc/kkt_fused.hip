@@ -206,6 +206,15 @@ __device__ inline int lane_id() {
   return l;
 }
 
+// The kernel's argument block as the hardware sees it (kernarg segment, constant address space), behind a pointer the
+// compiler cannot see through: loads through it stay where they are written instead of being hoisted to the kernel entry.
+typedef const KernelArgs __attribute__((address_space(4)))* KArgs;
+__device__ inline KArgs fresh_args() {
+  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // LDS-DMA: every lane's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * lane (no VGPR destination).
 // hipcc does not count this load: its completion is waited for by hand with wait_vmcnt<N>() (loads retire in order).
 __device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
@@ -268,60 +277,68 @@ __device__ inline void sweep_step(d4& T, bool& ok, int g, int j) {
 template <int LANE_IN_ROW> __device__ inline double row_bcast64(double v) {
   return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + LANE_IN_ROW, 0xf, 0xf, false));
 }
-__device__ inline void masked_set(double& dst, double src, unsigned long long mask) {  // dst = src in the lanes of `mask`
+// The lane masks are compile-time immediates (two s_mov_b32 literals): as SGPR operands hipcc keeps all twenty of them live
+// across the elimination, overflows the SGPR file and pays for it in v_readlane / v_writelane VALU work.
+template <unsigned long long MASK> __device__ inline void masked_set(double& dst, double src) {  // dst = src in the lanes of MASK
   unsigned long long save;
-  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[d], %[s]\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b64 %[d], %[s]\n\t"
+               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
                : [d] "+v"(dst), [sv] "=&s"(save)
-               : [s] "v"(src), [m] "s"(mask));
+               : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
-__device__ inline void masked_zero4(d4& T, unsigned long long mask) {  // T[0..3] = 0 in the lanes of `mask`
+template <unsigned long long MASK> __device__ inline void masked_zero4(d4& T) {  // T[0..3] = 0 in the lanes of MASK
   unsigned long long save;
   double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
   asm volatile(
-      "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tv_mov_b64 %[a], 0\n\tv_mov_b64 %[b], 0\n\tv_mov_b64 %[c], 0\n\t"
-      "v_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+      "s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b64 %[a], 0\n\tv_mov_b64 %[b], 0\n\t"
+      "v_mov_b64 %[c], 0\n\tv_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
       : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3), [sv] "=&s"(save)
-      : [m] "s"(mask));
+      : [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
   T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
 }
-template <int K>
-__device__ inline void sweep_step_lean(d4& T, bool& ok, int g, int j) {
+// `bad` accumulates 0 * (1/d): it turns NaN at a zero (or NaN) pivot and stays 0.0 otherwise -- one FMA per pivot instead
+// of a compare whose sixteen scalar results hipcc parks in spill lanes.  (An infinite pivot is not flagged here; it makes the
+// tile NaN and surfaces as MO_STATUS_NONFINITE.)
+template <int K, bool BPF>
+__device__ inline void sweep_step_lean(d4& T, double& bad, int g, int j) {
   constexpr int src_g = K & 3, src_t = K >> 2;
   constexpr unsigned long long mcol = 0x0001000100010001ull << K;           // the four lanes of tile column k (j == K)
-  const unsigned long long mrow = 0xFFFFull << (16 * src_g);                // the 16 lanes of the row group that holds row k
+  constexpr unsigned long long mrow = 0xFFFFull << (16 * src_g);            // the 16 lanes of the row group that holds row k
   const double rowreg = T[src_t];  // every broadcast below is taken before any register of T is modified
   const double d = readlane_f64(rowreg, 16 * src_g + K);
-  ok = ok && (fabs(d) > 0.0) && (fabs(d) < INFINITY);
   double inv = __builtin_amdgcn_rcp(d);
   inv = fma(inv, fma(-d, inv, 1.0), inv);  // one Newton step: |inv d - 1| < 2e-15 (tools/microbench.hip)
+  asm volatile("v_fma_f64 %0, %1, 0, %0" : "+v"(bad) : "v"(inv));  // volatile: hipcc would sink sixteen of these to the end
   double rk = bpermute_f64((16 * src_g + j) * 4, rowreg) * inv;  // T(k, j) / d for this lane's column j, in every row
-  masked_set(rk, -inv, mcol);
+  masked_set<mcol>(rk, -inv);
   double f[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) f[t] = row_bcast64<K>(T[t]);  // T(g + 4t, k): column k of this lane's own rows
-  masked_zero4(T, mcol);
+  for (int t = 0; t < 4; ++t)  // T(g + 4t, k): column k of this lane's own rows ( = T(k, g + 4t) by symmetry when BPF)
+    f[t] = BPF ? bpermute_f64(4 * g + (64 * src_g + 16 * t), rowreg) : row_bcast64<K>(T[t]);
+  masked_zero4<mcol>(T);
 #pragma unroll
   for (int t = 0; t < 4; ++t) T[t] = fma(-f[t], rk, T[t]);
   double rowk_new = T[src_t];
-  masked_set(rowk_new, rk, mrow);
+  masked_set<mrow>(rowk_new, rk);
   T[src_t] = rowk_new;
 }
 template <int K, int KEND, int SW> struct SweepLoop {
-  static __device__ inline void run(d4& T, bool& ok, int npiv, int g, int j) {
+  static __device__ inline void run(d4& T, bool& ok, double& bad, int npiv, int g, int j) {
     if (K < npiv) {  // wave-uniform
-      if (SW == 3) sweep_step_lean<K>(T, ok, g, j);
+      if (SW >= 3) sweep_step_lean<K, SW == 4>(T, bad, g, j);
       else sweep_step<K, SW>(T, ok, g, j);
     }
-    SweepLoop<K + 1, KEND, SW>::run(T, ok, npiv, g, j);
+    SweepLoop<K + 1, KEND, SW>::run(T, ok, bad, npiv, g, j);
   }
 };
 template <int KEND, int SW> struct SweepLoop<KEND, KEND, SW> {
-  static __device__ inline void run(d4&, bool&, int, int, int) {}
+  static __device__ inline void run(d4&, bool&, double&, int, int, int) {}
 };
 template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int j) {
   bool ok = true;
-  SweepLoop<0, 16, SW>::run(T, ok, npiv, g, j);
-  return ok;
+  double bad = 0.0;
+  SweepLoop<0, 16, SW>::run(T, ok, bad, npiv, g, j);
+  return ok && (bad == 0.0);
 }
 
 // ---- reusable components ----------------------------------------------------------------------------------------
@@ -543,8 +560,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 
     const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
     const double* rg = QPL ? nullptr : (const double*)a.r + p * a.r_stride;
-    const double* vp = (const double*)a.vars + p * a.vars_stride;
-    const double mu = a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0;
+    // Everything but the J stream's own operands is re-read from the kernarg segment where it is used (scalar loads, K$
+    // hits): held in SGPRs for the whole kernel they overflow the SGPR file and come back as v_readlane VALU work.
+    KArgs ka = fresh_args();
+    const double* vp = (const double*)ka->vars + p * ka->vars_stride;
 
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
     JStream<NT, D> stream;
@@ -560,18 +579,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
     dma_doubles(vp, vec_base, N, lane);                                                     // x -> xs
     if (m > 0) {
-      if (lane < m) dma4(a.cons_var + p * a.cons_stride + lane, vec_base + (3 * N + 256) * 8);
-      dma_doubles((const double*)a.cons_a + p * a.cons_stride, vec_base + (3 * N) * 8, m, lane);
-      dma_doubles((const double*)a.cons_b + p * a.cons_stride, vec_base + (3 * N + 64) * 8, m, lane);
+      const long long coff = p * ka->cons_stride;
+      if (lane < m) dma4(ka->cons_var + coff + lane, vec_base + (3 * N + 256) * 8);
+      dma_doubles((const double*)ka->cons_a + coff, vec_base + (3 * N) * 8, m, lane);
+      dma_doubles((const double*)ka->cons_b + coff, vec_base + (3 * N + 64) * 8, m, lane);
       dma_doubles(vp + N, vec_base + (3 * N + 128) * 8, m, lane);                            // s
       dma_doubles(vp + N + m + k, vec_base + (3 * N + 192) * 8, m, lane);                    // z
     }
     if (k > 0) {
       dma_doubles(vp + N + m, vec_base + (3 * N + 288) * 8, k, lane);                        // y
-      dma_doubles((const double*)a.b + p * a.b_stride, vec_base + (3 * N + 304) * 8, k, lane);  // b_eq
+      dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 304) * 8, k, lane);  // b_eq
     }
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
-    load_a_tiles<NT, QPL>(k > 0 ? (const double*)a.A + p * a.A_stride : nullptr, a.A_ld, k, g, j, U);
+    load_a_tiles<NT, QPL>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, g, j, U);
 
     MO_STAMP(0);
     // ---- P1: stream J once through the LDS-DMA ring; G = J^T J on the matrix cores (upper block triangle of tiles),
@@ -582,7 +602,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
     double cvec[NT];  // c (= J^T r) at position 16c + j (replicated over g)
     if (QPL) {
-      load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, g, j, U, cvec);
+      load_g_tiles<NT>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, g, j, U, cvec);
     } else {
       stream.run(U, cpart);
 #pragma unroll
@@ -592,6 +612,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 
     // ---- P3: per-constraint barrier terms, scattered per variable through LDS (duplicates on one variable accumulate)
     wait_vmcnt<0>();  // the P0 DMAs have landed (they are older than the last ring DMA the stream waited for)
+    ka = fresh_args();
+    const double mu = ka->mu ? ((const double*)ka->mu)[p * ka->mu_stride] : 0.0;
     if (lane < N / 2) {
       diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
       rhsS[2 * lane] = 0.0; rhsS[2 * lane + 1] = 0.0;
@@ -627,7 +649,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       if (g + 4 * t == kRC) v = (j < k) ? -bb[j] : 0.0;
       U[NT * NB + NT][t] = v;
     }
-    const double lam = (!QPL && a.lambda > 0.0) ? a.lambda : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
+    const double lam = (!QPL && ka->lambda > 0.0) ? ka->lambda : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
@@ -664,6 +686,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 
     MO_STAMP(5);
     // ---- P7: direction, step lengths, status
+    ka = fresh_args();
     double dxv[NT];
     {
       double xn[NT];
@@ -683,7 +706,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       const double r_pi = ca * xs[cvar] + cb - cs;                                  // qp.cc:416
       dsv = ca * dxs[cvar] + r_pi;                                                  // qp.cc:361
       dzv = -(cz * cs_inv) * dsv - cs_inv * (cs * cz - mu);                         // qp.cc:362
-      const double tau = a.tau;
+      const double tau = ka->tau;
       if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -tau * cs * rcp_f64(dsv);        // qp.cc:498-503
       if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -tau * cz * rcp_f64(dzv);
       finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
@@ -698,7 +721,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     if (slack_bad) st = MO_STATUS_NONPOSITIVE_SLACK;
     if (any_bad_index) st = MO_STATUS_BAD_INDEX;
     const double nanv = __builtin_nan("");
-    double* dp = (double*)a.delta + p * a.delta_stride;
+    double* dp = (double*)ka->delta + p * ka->delta_stride;
     if (g == 0) {
       double outv[NT];
 #pragma unroll
@@ -711,11 +734,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       dp[N + m + k + lane] = st == MO_STATUS_OK ? dzv : nanv;
     }
     if (lane == 0) {
-      if (a.alpha) {
-        ((double*)a.alpha)[2 * p] = st == MO_STATUS_OK ? ap : nanv;
-        ((double*)a.alpha)[2 * p + 1] = st == MO_STATUS_OK ? ad : nanv;
+      if (ka->alpha) {
+        ((double*)ka->alpha)[2 * p] = st == MO_STATUS_OK ? ap : nanv;
+        ((double*)ka->alpha)[2 * p + 1] = st == MO_STATUS_OK ? ad : nanv;
       }
-      if (a.status) a.status[p] = st;
+      if (ka->status) ka->status[p] = st;
     }
     lds_fence();  // LDS vectors are re-initialised by the next problem
     MO_STAMP(6);
