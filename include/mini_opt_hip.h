@@ -92,6 +92,8 @@ typedef struct {
   const void* A_eq;   int64_t A_stride; int32_t A_ld; int32_t reserved1; /* k x n col-major (NULL iff k == 0) */
   const void* b_eq;   int64_t b_stride;                                /* k */
   const int32_t* cons_var; const void* cons_a; const void* cons_b; int64_t cons_stride; /* m each: a*x[var]+b >= 0 */
+  const void* lambda_vec; int64_t lambda_stride; /* optional per-problem damping (the lambda state of nonlinear.cc:92-96);
+                                                    overrides `lambda` when non-NULL */
 } mo_problem;
 
 /* QPInteriorPointSolver::Params (qp.hpp:134-164); mo_default_solve_params fills the reference defaults. */
@@ -142,6 +144,27 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob);
  * c_out = J^T r, half_sq_out[p] = 0.5 |r|^2 (may be NULL). */
 int mo_linearize(mo_plan* plan, const mo_problem* prob, int64_t batch, void* G_out, int64_t G_stride, int32_t G_ld,
                  void* c_out, int64_t c_stride, void* half_sq_out, void* stream);
+
+/* Replaces the whole of LinearizeAndFillQP (nonlinear.cc:170-214) for dense residual stacks.  The caller hands over the cost
+ * stack (J, r, lambda[_vec]) and -- as prob->A_eq / prob->b_eq -- the equality residuals' Jacobian and values at the
+ * linearisation point x (UpdateJacobian, residual.hpp:230-250, is a plain copy for a dense stack), plus the problem's
+ * UNSHIFTED inequality constraints.  Written: G_out / c_out as mo_linearize; cons_b_out[m] = a * x[var] + b
+ * (LinearInequalityConstraint::ShiftTo, qp.hpp:57-65); errors_out[p] = {f = 0.5 |r|^2, equality = |b_eq|_1}
+ * (Errors, structs.hpp:169-186); status[p] = MO_STATUS_BAD_INDEX for a constraint variable outside [0, n). */
+int mo_fill_qp(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* x, int64_t x_stride, void* G_out,
+               int64_t G_stride, int32_t G_ld, void* c_out, int64_t c_stride, void* cons_b_out, int64_t cons_b_stride,
+               void* errors_out, int32_t* status, void* stream);
+
+/* Replaces EvaluateNonlinearErrors (nonlinear.cc:279-293) for dense residual stacks evaluated by the caller:
+ * errors_out[p] = {0.5 |r|^2, |r_eq|_1}.  r: m_r values per problem, r_eq: k values per problem (NULL iff k == 0). */
+int mo_nonlinear_errors(mo_plan* plan, const void* r, int64_t r_stride, const void* r_eq, int64_t r_eq_stride,
+                        int64_t batch, void* errors_out, void* stream);
+
+/* Replaces ComputeQPCostDerivative (nonlinear.cc:452-483): deriv_out[p] = {d_f = c^T dx, d_equality = sum_i sign(b_eq_i)
+ * (A_eq dx)_i} (DirectionalDerivatives, structs.hpp:189-203).  With J-level input c^T dx is evaluated as r^T (J dx).
+ * quad_out[p] (may be NULL) = dx^T G dx, the curvature term SelectPenalty needs (nonlinear.cc:496-498). */
+int mo_qp_cost_derivative(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* dx, int64_t dx_stride,
+                          void* deriv_out, void* quad_out, void* stream);
 
 /* Replaces EvaluateKKTConditions (qp.cc:391-420) + ComputeErrors (qp.cc:423-437):
  * r_out [V] = [r_d | r_comp | r_pe | r_pi] (mu NOT applied, as in the reference), kkt_out [4] (may be NULL) with mu[p]. */

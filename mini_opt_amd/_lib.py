@@ -23,7 +23,7 @@ MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
 # every symbol include/mini_opt_hip.h declares
 EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
            "mo_plan_destroy", "mo_plan_step_kernel", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
-           "mo_qp_solve"]
+           "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative"]
 
 
 class PlanDesc(C.Structure):
@@ -39,7 +39,8 @@ class Problem(C.Structure):
                 ("c", C.c_void_p), ("c_stride", C.c_int64),
                 ("A_eq", C.c_void_p), ("A_stride", C.c_int64), ("A_ld", C.c_int32), ("reserved1", C.c_int32),
                 ("b_eq", C.c_void_p), ("b_stride", C.c_int64),
-                ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64)]
+                ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64),
+                ("lambda_vec", C.c_void_p), ("lambda_stride", C.c_int64)]
 
 
 class SolveParams(C.Structure):
@@ -89,6 +90,9 @@ def lib() -> C.CDLL:
     L.mo_newton_step.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, dbl, u32, vp, i64, vp, vp, vp]
     L.mo_iterate.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp]
     L.mo_qp_solve.argtypes = [vp, C.POINTER(Problem), i64, C.POINTER(SolveParams), vp, i64, vp, vp, vp, vp, vp, vp]
+    L.mo_fill_qp.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp, vp, vp]
+    L.mo_nonlinear_errors.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp]
+    L.mo_qp_cost_derivative.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the library does not export what the header declares
     _lib = L

@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       if (g + 4 * t == kRC) v = (j < k) ? -bb[j] : 0.0;
       U[NT * NB + NT][t] = v;
     }
-    const double lam = (!QPL && ka->lambda > 0.0) ? ka->lambda : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
+    const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
+    const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
@@ -835,7 +836,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
     const double* rg = QPL ? nullptr : (const double*)a.r + p * a.r_stride;
     double* vp = (double*)a.vars + p * a.vars_stride;
-    const double lam = (!QPL && a.lambda > 0.0) ? a.lambda : 0.0;  // a given G already carries the LM damping
+    const double lam_in = a.lambda_vec ? ((const double*)a.lambda_vec)[p * a.lambda_vec_stride] : a.lambda;
+    const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // a given G already carries the LM damping
 
     // ---- constants of the problem
     int cvar = 0; double ca = 1.0, cb = 0.0;

@@ -517,7 +517,8 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
     load_qp(w, n, k, j_level ? (const T*)nullptr : Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
     MO_GSTAMP(1);
     if (j_level) {
-      accumulate_jtj(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, (T)a.lambda, tid);
+      const T lam = a.lambda_vec ? ((const T*)a.lambda_vec)[p * a.lambda_vec_stride] : (T)a.lambda;  // per-problem LM state
+      accumulate_jtj(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, lam, tid);
       MO_GSTAMP(2);
       if (MODE == MODE_LINEARIZE || MODE == MODE_SOLVE) {
         // LINEARIZE output, or the per-problem G scratch the Solve loop reloads after each factorisation
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
           for (int i = tid; i < n; i += kThreads) Go[i + (size_t)j * a.G_out_ld] = i >= j ? w.H[i + (size_t)j * w.ldh] : (T)0;
         T* co = (T*)a.c_out + p * a.c_out_stride;
         for (int i = tid; i < n; i += kThreads) co[i] = w.cvec[i];
-        if (a.half_sq_out && tid == 0) ((T*)a.half_sq_out)[p] = w.red[8];
+        if (a.half_sq_out && tid == 0) ((T*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = w.red[8];
         Gp = Go; cp = co; G_ld = a.G_out_ld;
         __threadfence();  // the Solve loop re-reads this scratch from other threads of the workgroup
         __syncthreads();

@@ -67,6 +67,7 @@ int fill_problem(const mo_plan* plan, const mo_problem* prob, int64_t batch, boo
       if (prob->J_ld < min_ld) return fail(MO_ERR_DIMENSION, "J_ld %d < %d", prob->J_ld, min_ld);
       a->J = prob->J; a->J_stride = prob->J_stride; a->J_ld = prob->J_ld; a->J_row_major = prob->J_layout == MO_ROW_MAJOR;
       a->r = prob->r; a->r_stride = prob->r_stride; a->lambda = prob->lambda; a->m_r = d.m_r;
+      a->lambda_vec = prob->lambda_vec; a->lambda_vec_stride = prob->lambda_stride;
     } else {
       if (!prob->G || !prob->c) return fail(MO_ERR_INVALID_ARGUMENT, "need either (J, r) or (G, c)");
       if (prob->G_ld < d.n) return fail(MO_ERR_DIMENSION, "G must be square: G_ld %d < n %d", prob->G_ld, d.n);
@@ -213,6 +214,82 @@ int mo_linearize(mo_plan* plan, const mo_problem* prob, int64_t batch, void* G_o
   a.G_out = G_out; a.G_out_stride = G_stride; a.G_out_ld = G_ld;
   a.c_out = c_out; a.c_out_stride = c_stride; a.half_sq_out = half_sq_out;
   return launch(&tmp, a, stream);
+}
+
+int mo_fill_qp(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* x, int64_t x_stride, void* G_out,
+               int64_t G_stride, int32_t G_ld, void* c_out, int64_t c_stride, void* cons_b_out, int64_t cons_b_stride,
+               void* errors_out, int32_t* status, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  if (!prob || !prob->J) return fail(MO_ERR_INVALID_ARGUMENT, "mo_fill_qp needs the cost residual stack (J, r)");
+  if (!errors_out) return fail(MO_ERR_INVALID_ARGUMENT, "errors_out is NULL");
+  const mo_plan_desc& d = plan->desc;
+  if (d.m > 0 && (!x || !cons_b_out)) return fail(MO_ERR_INVALID_ARGUMENT, "x / cons_b_out is NULL");
+  mo::KernelArgs ka;
+  if (int rc = fill_problem(plan, prob, batch, true, true, &ka)) return rc;  // validates A_eq / b_eq / constraints too
+  // cost part: G = J^T J + lambda I, c = J^T r, f = 0.5 |r|^2 (nonlinear.cc:182-189) -> errors_out[2 p]
+  mo_plan tmp = *plan;
+  tmp.desc.k = 0; tmp.desc.m = 0;
+  mo::KernelArgs a;
+  if (int rc = fill_problem(&tmp, prob, batch, true, false, &a)) return rc;
+  if (!G_out || !c_out) return fail(MO_ERR_INVALID_ARGUMENT, "G_out / c_out is NULL");
+  if (G_ld < d.n) return fail(MO_ERR_DIMENSION, "G_ld %d < n", G_ld);
+  a.mode = mo::MODE_LINEARIZE;
+  a.G_out = G_out; a.G_out_stride = G_stride; a.G_out_ld = G_ld;
+  a.c_out = c_out; a.c_out_stride = c_stride; a.half_sq_out = errors_out; a.half_sq_stride = 2;
+  if (int rc = launch(&tmp, a, stream)) return rc;
+  if (batch == 0) return MO_OK;
+  // tail: shifted constraints and the equality L1 norm (nonlinear.cc:192-212)
+  mo::AuxArgs x_args;
+  memset(&x_args, 0, sizeof(x_args));
+  x_args.n = d.n; x_args.k = d.k; x_args.m = d.m; x_args.batch = batch;
+  x_args.x = x; x_args.x_stride = x_stride;
+  x_args.b = ka.b; x_args.b_stride = ka.b_stride;
+  x_args.cons_var = ka.cons_var; x_args.cons_a = ka.cons_a; x_args.cons_b = ka.cons_b; x_args.cons_stride = ka.cons_stride;
+  x_args.cons_b_out = cons_b_out; x_args.cons_b_out_stride = cons_b_stride;
+  x_args.out2 = errors_out; x_args.status = status;
+  MO_HIP_CHECK(mo::launch_shift_constraints(x_args, d.dtype, (hipStream_t)stream));
+  return MO_OK;
+}
+
+int mo_nonlinear_errors(mo_plan* plan, const void* r, int64_t r_stride, const void* r_eq, int64_t r_eq_stride,
+                        int64_t batch, void* errors_out, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  const mo_plan_desc& d = plan->desc;
+  if (batch < 0) return fail(MO_ERR_INVALID_ARGUMENT, "batch must be >= 0");
+  if (!errors_out) return fail(MO_ERR_INVALID_ARGUMENT, "errors_out is NULL");
+  if (d.m_r > 0 && !r) return fail(MO_ERR_INVALID_ARGUMENT, "r is NULL");
+  if (d.k > 0 && !r_eq) return fail(MO_ERR_DIMENSION, "k = %d but r_eq is NULL", d.k);
+  mo::AuxArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = d.n; a.k = d.k; a.m = d.m; a.m_r = d.m_r; a.batch = batch;
+  a.r = r; a.r_stride = r_stride; a.b = r_eq; a.b_stride = r_eq_stride; a.out2 = errors_out;
+  MO_HIP_CHECK(hipSetDevice(d.device));
+  MO_HIP_CHECK(mo::launch_nonlinear_errors(a, d.dtype, (hipStream_t)stream));
+  return MO_OK;
+}
+
+int mo_qp_cost_derivative(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* dx, int64_t dx_stride,
+                          void* deriv_out, void* quad_out, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  const mo_plan_desc& d = plan->desc;
+  mo::KernelArgs ka;
+  if (int rc = fill_problem(plan, prob, batch, true, false, &ka)) return rc;
+  if (!dx || !deriv_out) return fail(MO_ERR_INVALID_ARGUMENT, "dx / deriv_out is NULL");  // F_ASSERT_EQ(qp.c.rows(), dx.rows())
+  mo::AuxArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = d.n; a.k = d.k; a.m = d.m; a.m_r = ka.m_r; a.batch = batch;
+  a.x = dx; a.x_stride = dx_stride;
+  a.J = ka.J; a.J_stride = ka.J_stride; a.J_ld = ka.J_ld; a.J_row_major = ka.J_row_major; a.r = ka.r; a.r_stride = ka.r_stride;
+  a.G = ka.G; a.G_stride = ka.G_stride; a.G_ld = ka.G_ld; a.c = ka.c; a.c_stride = ka.c_stride;
+  a.A = ka.A; a.A_stride = ka.A_stride; a.A_ld = ka.A_ld; a.b = ka.b; a.b_stride = ka.b_stride;
+  a.lambda = ka.lambda; a.lambda_vec = ka.lambda_vec; a.lambda_vec_stride = ka.lambda_vec_stride;
+  a.out2 = deriv_out; a.quad_out = quad_out;
+  MO_HIP_CHECK(hipSetDevice(d.device));
+  MO_HIP_CHECK(mo::launch_cost_derivative(a, d.dtype, (hipStream_t)stream));
+  return MO_OK;
 }
 
 int mo_kkt_residual(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* vars, int64_t vars_stride,

@@ -25,6 +25,7 @@ struct KernelArgs {
   const void* J; long long J_stride; int J_ld; int J_row_major;
   const void* r; long long r_stride;
   double lambda;
+  const void* lambda_vec; long long lambda_vec_stride;  // per-problem damping, overrides lambda when non-NULL
   const void* G; long long G_stride; int G_ld;
   const void* c; long long c_stride;
   const void* A; long long A_stride; int A_ld;
@@ -44,7 +45,7 @@ struct KernelArgs {
   void* kkt_out;   // [batch][4]
   void* G_out; long long G_out_stride; int G_out_ld;  // MODE_LINEARIZE (also SOLVE scratch for J-level input)
   void* c_out; long long c_out_stride;
-  void* half_sq_out;
+  void* half_sq_out; long long half_sq_stride;  // stride in elements (0 means 1)
   // MODE_SOLVE
   mo_solve_params sp;
   int* termination; int* num_iterations; void* iterations; void* lagrange;
@@ -62,5 +63,28 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
 bool fused_supported(const KernelArgs& a, int dtype);
 const char* fused_name(const KernelArgs& a, int dtype);
 hipError_t launch_fused(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
+
+
+// small per-problem kernels around the QP (LinearizeAndFillQP tail, EvaluateNonlinearErrors, ComputeQPCostDerivative), nls_kernels.hip
+struct AuxArgs {
+  int n, k, m, m_r;
+  long long batch;
+  const void* x; long long x_stride;                  // linearisation point / direction dx
+  const void* J; long long J_stride; int J_ld; int J_row_major;
+  const void* r; long long r_stride;
+  const void* G; long long G_stride; int G_ld;
+  const void* c; long long c_stride;
+  const void* A; long long A_stride; int A_ld;
+  const void* b; long long b_stride;                  // b_eq or r_eq
+  const int* cons_var; const void* cons_a; const void* cons_b; long long cons_stride;
+  double lambda; const void* lambda_vec; long long lambda_vec_stride;
+  void* cons_b_out; long long cons_b_out_stride;
+  void* out2;                                         // [batch][2]
+  void* quad_out;                                     // [batch]
+  int* status;
+};
+hipError_t launch_shift_constraints(const AuxArgs& a, int dtype, hipStream_t stream);
+hipError_t launch_nonlinear_errors(const AuxArgs& a, int dtype, hipStream_t stream);
+hipError_t launch_cost_derivative(const AuxArgs& a, int dtype, hipStream_t stream);
 
 }  // namespace mo

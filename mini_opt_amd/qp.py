@@ -54,6 +54,7 @@ class BatchedQP:
     J: Optional[torch.Tensor] = None
     r: Optional[torch.Tensor] = None
     lam: float = 0.0
+    lam_vec: Optional[torch.Tensor] = None   # [B] per-problem damping; overrides lam (the lambda state of nonlinear.cc:92-96)
     G: Optional[torch.Tensor] = None
     c: Optional[torch.Tensor] = None
     A_eq: Optional[torch.Tensor] = None
@@ -112,6 +113,9 @@ class BatchedQP:
             p.J, p.J_stride, p.J_ld, p.J_layout = _ptr(self.J), stride(self.J, self.m_r * n), n, L.MO_ROW_MAJOR
             p.r, p.r_stride = _ptr(self.r), stride(self.r, self.m_r)
             p.lam = float(self.lam)
+            if self.lam_vec is not None:
+                chk(self.lam_vec, ())
+                p.lambda_vec, p.lambda_stride = _ptr(self.lam_vec), stride(self.lam_vec, 1)
         else:
             chk(self.G, (n, n)); chk(self.c, (n,))
             p.G, p.G_stride, p.G_ld = _ptr(self.G), stride(self.G, n * n), n

@@ -1,0 +1,111 @@
+"""The NLS oracle (oracle/nls_oracle.py) replays the reference's own NLS tests (nonlinear_test.cc:390-826): termination class
+and optimum of every named problem, plus the polynomial line-search helpers' known answers (nonlinear_test.cc:185-272)."""
+import numpy as np
+import pytest
+
+from oracle import nls_oracle as N
+from tests import nls_problems as P
+
+SATISFIED = (N.SATISFIED_ABSOLUTE_TOL, N.SATISFIED_RELATIVE_TOL, N.SATISFIED_FIRST_ORDER_TOL)
+
+
+def test_quadratic_and_cubic_helpers():
+    # nonlinear_test.cc:185-209
+    alpha_0, phi_0, phi_prime_0, phi_alpha_0 = 0.8, 2.0, -1.2, 2.2
+    sol = N.quadratic_approx_minimum(phi_0, phi_prime_0, alpha_0, phi_alpha_0)
+    a = (phi_alpha_0 - phi_0 - alpha_0 * phi_prime_0) / alpha_0 ** 2
+    assert abs(-phi_prime_0 / (2 * a) - sol) < 1e-12
+    # cubic through four conditions reproduces its own coefficients (nonlinear_test.cc:211-272)
+    ca, cb, c1, c0 = 0.7, -1.3, -0.4, 2.0
+    phi = lambda t: ca * t ** 3 + cb * t ** 2 + c1 * t + c0
+    ab = N.cubic_approx_coeffs(c0, c1, 0.9, phi(0.9), 0.35, phi(0.35))
+    np.testing.assert_allclose(ab, [ca, cb], rtol=1e-10)
+    t = N.cubic_approx_minimum(c1, ab)
+    assert abs(3 * ca * t * t + 2 * cb * t + c1) < 1e-10 and 6 * ca * t + 2 * cb > 0
+
+
+def test_cost_derivative_matches_numerical():
+    # nonlinear_test.cc:109-183: d/dalpha [0.5 |h|^2 + penalty |c|_1] at alpha = 0 along dx
+    rng = np.random.default_rng(0)
+    x = np.array([1.1, -0.4]); dx = np.array([0.3, -0.7])
+    prob = N.Problem(2, P.rosenbrock_np, equality=lambda v, w: (np.array([v[0] * v[1] - 0.3]), np.array([[v[1], v[0]]]) if w else None))
+    qp, _ = N.linearize_and_fill_qp(x, 0.0, prob)
+    d_f, d_eq = N.compute_qp_cost_derivative(qp, dx)
+    h = 1e-6
+    tot = lambda al: N.evaluate_nonlinear_errors(prob, x + al * dx).total(0.334)
+    num = (tot(h) - tot(-h)) / (2 * h)
+    assert abs(num - (d_f + 0.334 * d_eq)) < 1e-6
+
+
+@pytest.mark.parametrize("guess", P.ROSENBROCK_GUESSES)
+def test_rosenbrock(guess):
+    nls = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.rosenbrock_np))
+    term, logs = nls.solve(N.Params(max_iterations=5, max_qp_iterations=1), guess)
+    assert term == N.SATISFIED_ABSOLUTE_TOL
+    np.testing.assert_allclose(nls.variables, [1, 1], atol=1e-6)
+
+
+@pytest.mark.parametrize("guess", P.ROSENBROCK_GUESSES)
+def test_rosenbrock_lm(guess):
+    nls = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.rosenbrock_np))
+    term, logs = nls.solve(N.Params(max_iterations=10, max_qp_iterations=1, absolute_first_derivative_tol=1e-12,
+                                    max_line_search_iterations=0), guess)
+    assert term == N.SATISFIED_ABSOLUTE_TOL
+    np.testing.assert_allclose(nls.variables, [1, 1], atol=1e-6)
+
+
+@pytest.mark.parametrize("guess", P.ROSENBROCK_CONSTRAINED_GUESSES)
+def test_inequality_constrained_rosenbrock(guess):
+    prob = N.Problem(2, P.rosenbrock_np, inequality_constraints=[(0, 1.0, -1.2), (1, -1.0, 0.5)])
+    nls = N.ConstrainedNonlinearLeastSquares(prob)
+    term, logs = nls.solve(N.Params(max_iterations=10, max_qp_iterations=10), guess)
+    assert term not in (N.MAX_ITERATIONS, N.MAX_LAMBDA)
+    np.testing.assert_allclose(nls.variables, [1.2, 0.5], atol=1e-6)
+
+
+@pytest.mark.parametrize("guess", P.ROSENBROCK6_GUESSES)
+def test_inequality_constrained_rosenbrock_6d(guess):
+    prob = N.Problem(6, P.rosenbrock6_np, inequality_constraints=P.ROSENBROCK6_CONSTRAINTS)
+    nls = N.ConstrainedNonlinearLeastSquares(prob)
+    term, logs = nls.solve(N.Params(max_iterations=30, max_qp_iterations=30, relative_exit_tol=1e-6,
+                                    absolute_first_derivative_tol=5e-6, termination_kkt_tolerance=1e-6, max_lambda=10.0), guess)
+    assert term in SATISFIED
+    np.testing.assert_allclose(nls.variables, P.ROSENBROCK6_SOLUTION, atol=1e-5)
+
+
+def test_himmelblau_grid():
+    prob = N.Problem(2, P.himmelblau_np, inequality_constraints=P.box(-5.0, 5.0))
+    for sol in P.HIMMELBLAU_SOLUTIONS:
+        assert N.evaluate_nonlinear_errors(prob, np.array(sol)).total(1.0) < 1e-6
+    params = N.Params(max_iterations=20, max_qp_iterations=10, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-8,
+                      termination_kkt_tolerance=1e-6)
+    nls = N.ConstrainedNonlinearLeastSquares(prob)
+    for guess in P.himmelblau_guesses():
+        term, logs = nls.solve(params, guess)
+        assert term in SATISFIED, (guess, term)
+        best = min(P.HIMMELBLAU_SOLUTIONS, key=lambda s: np.linalg.norm(np.array(s) - nls.variables))
+        np.testing.assert_allclose(nls.variables, best, atol=5e-5, err_msg=str(guess))
+
+
+def test_himmelblau_quadrant():
+    prob = N.Problem(2, P.himmelblau_np, inequality_constraints=P.box(0.1, 5.0))
+    params = N.Params(max_iterations=20, max_qp_iterations=10, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-8,
+                      termination_kkt_tolerance=1e-6)
+    nls = N.ConstrainedNonlinearLeastSquares(prob)
+    for guess in P.himmelblau_quadrant_guesses():
+        term, logs = nls.solve(params, guess)
+        assert term in SATISFIED, (guess, term)
+        np.testing.assert_allclose(nls.variables, [3.0, 2.0], atol=5e-5, err_msg=str(guess))
+
+
+def test_sphere_with_nonlinear_equality_constraints():
+    prob = N.Problem(6, P.sphere_np, equality=P.sphere_eq_np)
+    params = N.Params(max_iterations=100, max_qp_iterations=1, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-9,
+                      termination_kkt_tolerance=1e-6, lambda_initial=0.001)
+    nls = N.ConstrainedNonlinearLeastSquares(prob)
+    for guess in P.sphere_guesses(40):
+        term, logs = nls.solve(params, guess)
+        assert term in SATISFIED, (guess, term)
+        best = min(P.SPHERE_SOLUTIONS, key=lambda s: np.linalg.norm(np.array(s) - nls.variables))
+        np.testing.assert_allclose(nls.variables, best, atol=5e-5, err_msg=str(guess))
+        assert all(l.step_result not in (N.STEP_MAX_ITERATIONS, N.STEP_POSITIVE_DERIVATIVE) for l in logs)   # no failed line searches
