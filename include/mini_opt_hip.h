@@ -205,6 +205,79 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
                 int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
                 int32_t* status, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Batched constrained nonlinear least squares: ConstrainedNonlinearLeastSquares::Solve (nonlinear.cc:75-158) for a batch of
+ * independent problems of one shape, every problem with its own lambda / penalty / optimizer state, in lock step.
+ * The residual functions stay with the caller (the reference's Residual objects are host functors, residual.hpp:28-143):
+ * `eval` is called on the host and must ENQUEUE, on `stream`, device work that fills the buffers named in mo_nls_problem:
+ *   MO_NLS_EVAL_LINEARIZE : J, r (cost stack) and J_eq, r_eq (equality stack) at `vars`        (LinearizeAndFillQP)
+ *   MO_NLS_EVAL_ERRORS    : r_cand, r_eq_cand at `candidate`                                   (EvaluateNonlinearErrors)
+ * for ALL problems of the batch (finished problems are ignored afterwards).  Everything else -- the errors, the shifted
+ * constraints, the interior-point QP (mo_qp_solve), directional derivatives, penalty selection, the line search with
+ * quadratic / cubic interpolation, the lambda state machine and the exit tests -- runs on the device.
+ * fp64 plans only.  A problem whose QP fails (status != MO_STATUS_OK; the reference throws there) ends with
+ * MO_NLS_QP_FAILURE and its QP status in status[p].  With equality constraints and no inequalities the reference switches
+ * to QPNullSpaceSolver (nonlinear.cc:83-86); here the same step comes from the KKT factorisation and the penalty follows
+ * the no-multiplier branch of SelectPenalty (nonlinear.cc:491-499) as the reference's does; QP_INDEFINITE is not detected. */
+typedef enum { MO_NLS_MAX_ITERATIONS = 0, MO_NLS_SATISFIED_ABSOLUTE_TOL = 1, MO_NLS_SATISFIED_RELATIVE_TOL = 2,
+               MO_NLS_SATISFIED_FIRST_ORDER_TOL = 3, MO_NLS_MAX_LAMBDA = 4, MO_NLS_QP_INDEFINITE = 5,
+               MO_NLS_USER_CALLBACK = 6, MO_NLS_QP_FAILURE = 7 } mo_nls_termination;   /* NLSTerminationState, structs.hpp:233-248 */
+typedef enum { MO_LS_SUCCESS = 0, MO_LS_MAX_ITERATIONS = 1, MO_LS_FIRST_ORDER_SATISFIED = 2, MO_LS_POSITIVE_DERIVATIVE = 3,
+               MO_LS_FAILURE_NON_FINITE_COST = 4, MO_LS_FAILURE_INVALID_ALPHA = 5 } mo_step_result; /* StepSizeSelectionResult, structs.hpp:215-228 */
+typedef enum { MO_ARMIJO_BACKTRACK = 0, MO_POLYNOMIAL_APPROXIMATION = 1 } mo_line_search;      /* structs.hpp:148-153 */
+typedef enum { MO_NLS_EVAL_LINEARIZE = 0, MO_NLS_EVAL_ERRORS = 1 } mo_nls_eval;
+
+/* ConstrainedNonlinearLeastSquares::Params (nonlinear.hpp:64-124); mo_default_nls_params fills the reference defaults. */
+typedef struct {
+  int32_t max_iterations;
+  int32_t max_qp_iterations;
+  double termination_kkt_tolerance;
+  double absolute_exit_tol;
+  double relative_exit_tol;
+  double absolute_first_derivative_tol;
+  int32_t max_line_search_iterations;
+  int32_t line_search_strategy;        /* mo_line_search */
+  double armijo_search_tau;
+  double equality_penalty_initial;
+  double equality_penalty_scale_factor;
+  double equality_penalty_rho;
+  double lambda_initial;
+  double lambda_failure_init;
+  double lambda_decrease_on_success;
+  double lambda_decrease_on_restore;
+  double max_lambda;
+  double min_lambda;
+} mo_nls_params;
+
+/* Device buffers of one batch (all owned by the caller; shapes per problem, strides in elements, plan dims n, k, m, m_r). */
+typedef struct {
+  void* vars;      int64_t vars_stride;      /* n : in = initial guess, out = solution (Solve(params, variables), variables()) */
+  void* candidate; int64_t candidate_stride; /* n : the line search's trial point (RetractCandidateVars, nonlinear.cc:160-168) */
+  void* J;     int64_t J_stride; int32_t J_ld; int32_t J_layout;   /* m_r x n, filled by eval(LINEARIZE) */
+  void* r;     int64_t r_stride;                                  /* m_r */
+  void* J_eq;  int64_t J_eq_stride; int32_t J_eq_ld; int32_t reserved0; /* k x n column-major (= QP::A_eq), eval(LINEARIZE) */
+  void* r_eq;  int64_t r_eq_stride;                                /* k (= QP::b_eq) */
+  void* r_cand;    int64_t r_cand_stride;    /* m_r, filled by eval(ERRORS) */
+  void* r_eq_cand; int64_t r_eq_cand_stride; /* k */
+  const int32_t* cons_var; const void* cons_a; const void* cons_b; int64_t cons_stride; /* m: Problem::inequality_constraints */
+} mo_nls_problem;
+
+typedef int (*mo_nls_eval_fn)(void* user, int32_t what, void* stream);  /* non-zero return aborts mo_nls_solve with MO_ERR_CALLBACK */
+#define MO_ERR_CALLBACK (-6)
+
+/* NLSIteration (structs.hpp:277-330) as doubles: {optimizer_state, lambda, errors_initial.f, errors_initial.equality, d_f,
+ * d_equality, penalty, step_result, n_line_search_steps, qp_termination, qp_num_iterations, qp_status} followed by
+ * (max_line_search_iterations + 1) x {alpha, f, equality} (LineSearchStep, structs.hpp:206-213; NaN when not taken). */
+#define MO_NLS_ITER_HEADER 12
+#define MO_NLS_ITER_RECORD(max_line_search_iterations) (MO_NLS_ITER_HEADER + 3 * ((max_line_search_iterations) + 1))
+
+void mo_default_nls_params(mo_nls_params* params);
+/* termination [batch] (mo_nls_termination), num_iterations [batch], iterations [batch][max_iterations][MO_NLS_ITER_RECORD]
+ * (may be NULL), status [batch] (may be NULL).  Synchronises `stream` (one small read-back per outer iteration and per
+ * line-search step to learn whether any problem is still active). */
+int mo_nls_solve(mo_plan* plan, const mo_nls_problem* prob, int64_t batch, const mo_nls_params* params, mo_nls_eval_fn eval,
+                 void* user, int32_t* termination, int32_t* num_iterations, void* iterations, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

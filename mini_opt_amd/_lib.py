@@ -23,7 +23,8 @@ MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
 # every symbol include/mini_opt_hip.h declares
 EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
            "mo_plan_destroy", "mo_plan_step_kernel", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
-           "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative"]
+           "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative",
+           "mo_default_nls_params", "mo_nls_solve"]
 
 
 class PlanDesc(C.Structure):
@@ -49,6 +50,32 @@ class SolveParams(C.Structure):
                 ("barrier_strategy", C.c_int32), ("decrease_mu_only_on_small_error", C.c_int32),
                 ("initial_guess_method", C.c_int32), ("initialize_mu_with_complementarity", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class NlsParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("max_qp_iterations", C.c_int32), ("termination_kkt_tolerance", C.c_double),
+                ("absolute_exit_tol", C.c_double), ("relative_exit_tol", C.c_double),
+                ("absolute_first_derivative_tol", C.c_double), ("max_line_search_iterations", C.c_int32),
+                ("line_search_strategy", C.c_int32), ("armijo_search_tau", C.c_double),
+                ("equality_penalty_initial", C.c_double), ("equality_penalty_scale_factor", C.c_double),
+                ("equality_penalty_rho", C.c_double), ("lambda_initial", C.c_double), ("lambda_failure_init", C.c_double),
+                ("lambda_decrease_on_success", C.c_double), ("lambda_decrease_on_restore", C.c_double),
+                ("max_lambda", C.c_double), ("min_lambda", C.c_double)]
+
+
+class NlsProblem(C.Structure):
+    _fields_ = [("vars", C.c_void_p), ("vars_stride", C.c_int64), ("candidate", C.c_void_p), ("candidate_stride", C.c_int64),
+                ("J", C.c_void_p), ("J_stride", C.c_int64), ("J_ld", C.c_int32), ("J_layout", C.c_int32),
+                ("r", C.c_void_p), ("r_stride", C.c_int64),
+                ("J_eq", C.c_void_p), ("J_eq_stride", C.c_int64), ("J_eq_ld", C.c_int32), ("reserved0", C.c_int32),
+                ("r_eq", C.c_void_p), ("r_eq_stride", C.c_int64),
+                ("r_cand", C.c_void_p), ("r_cand_stride", C.c_int64), ("r_eq_cand", C.c_void_p), ("r_eq_cand_stride", C.c_int64),
+                ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64)]
+
+
+NLS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
+MO_NLS_EVAL_LINEARIZE, MO_NLS_EVAL_ERRORS = 0, 1
+MO_NLS_ITER_HEADER = 12
 
 
 def build(force: bool = False) -> str:
@@ -93,6 +120,9 @@ def lib() -> C.CDLL:
     L.mo_fill_qp.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp, vp, vp]
     L.mo_nonlinear_errors.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp]
     L.mo_qp_cost_derivative.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp, vp]
+    L.mo_default_nls_params.argtypes = [C.POINTER(NlsParams)]
+    L.mo_default_nls_params.restype = None
+    L.mo_nls_solve.argtypes = [vp, C.POINTER(NlsProblem), i64, C.POINTER(NlsParams), NLS_EVAL_FN, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the library does not export what the header declares
     _lib = L

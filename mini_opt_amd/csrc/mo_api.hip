@@ -106,6 +106,21 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
 
 }  // namespace
 
+namespace {
+// scratch of one mo_nls_solve call, released on every exit path
+struct NlsScratch {
+  void* ptrs[24];
+  int count = 0;
+  ~NlsScratch() { for (int i = 0; i < count; ++i) (void)hipFree(ptrs[i]); }
+  template <typename T> hipError_t alloc(T** out, size_t elems) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (elems ? elems : 1) * sizeof(T));
+    if (e == hipSuccess) { ptrs[count++] = p; *out = (T*)p; }
+    return e;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 const char* mo_version_string(void) { return "mini_opt_hip 0.1 (gfx950)"; }
@@ -384,6 +399,173 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
   }
   return launch(plan, a, stream);  // fused Solve kernel for J-level n = 32 / 64 fp64 problems, generic kernel otherwise
+}
+
+void mo_default_nls_params(mo_nls_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->max_iterations = 10;  // nonlinear.hpp:64-124
+  p->max_qp_iterations = 10;
+  p->termination_kkt_tolerance = 1.0e-6;
+  p->absolute_exit_tol = 1.0e-12;
+  p->relative_exit_tol = 1.0e-5;
+  p->absolute_first_derivative_tol = 1.0e-6;
+  p->max_line_search_iterations = 2;
+  p->line_search_strategy = MO_POLYNOMIAL_APPROXIMATION;
+  p->armijo_search_tau = 0.8;
+  p->equality_penalty_initial = 1.0;
+  p->equality_penalty_scale_factor = 1.01;
+  p->equality_penalty_rho = 0.1;
+  p->lambda_initial = 0.0;
+  p->lambda_failure_init = 1.0e-2;
+  p->lambda_decrease_on_success = 0.1;
+  p->lambda_decrease_on_restore = 0.8;
+  p->max_lambda = 1.0;
+  p->min_lambda = 0.0;
+}
+
+
+int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const mo_nls_params* prm, mo_nls_eval_fn eval,
+                 void* user, int32_t* termination, int32_t* num_iterations, void* iterations, int32_t* status, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  const mo_plan_desc& d = plan->desc;
+  if (d.dtype != MO_F64) return fail(MO_ERR_UNSUPPORTED, "mo_nls_solve needs an fp64 plan");
+  if (!np || !prm || !eval) return fail(MO_ERR_INVALID_ARGUMENT, "problem / params / eval is NULL");
+  if (batch < 0) return fail(MO_ERR_INVALID_ARGUMENT, "batch must be >= 0");
+  if (d.m_r <= 0) return fail(MO_ERR_DIMENSION, "the plan must be created with m_r > 0 (the cost residual stack)");
+  // CheckParams, nonlinear.cc:48-73
+  if (prm->max_iterations < 0) return fail(MO_ERR_INVALID_ARGUMENT, "max_iterations must be >= 0");
+  if (prm->max_qp_iterations < 1) return fail(MO_ERR_INVALID_ARGUMENT, "max_qp_iterations must be >= 1");
+  if (!(prm->termination_kkt_tolerance > 0)) return fail(MO_ERR_INVALID_ARGUMENT, "termination_kkt_tolerance must be > 0");
+  if (!(prm->absolute_exit_tol > 0)) return fail(MO_ERR_INVALID_ARGUMENT, "absolute_exit_tol must be > 0");
+  if (prm->max_line_search_iterations < 0) return fail(MO_ERR_INVALID_ARGUMENT, "max_line_search_iterations must be >= 0");
+  if (!(prm->relative_exit_tol >= 0) || !(prm->relative_exit_tol <= 1)) return fail(MO_ERR_INVALID_ARGUMENT, "relative_exit_tol must be in [0, 1]");
+  if (!(prm->absolute_first_derivative_tol >= 0)) return fail(MO_ERR_INVALID_ARGUMENT, "absolute_first_derivative_tol must be >= 0");
+  if (!(prm->armijo_search_tau > 0) || !(prm->armijo_search_tau < 1)) return fail(MO_ERR_INVALID_ARGUMENT, "armijo_search_tau must be in (0, 1)");
+  if (!(prm->equality_penalty_initial >= 0)) return fail(MO_ERR_INVALID_ARGUMENT, "equality_penalty_initial must be >= 0");
+  if (!(prm->equality_penalty_scale_factor >= 1.0)) return fail(MO_ERR_INVALID_ARGUMENT, "equality_penalty_scale_factor must be >= 1");
+  if (!(prm->equality_penalty_rho >= 0) || !(prm->equality_penalty_rho < 1)) return fail(MO_ERR_INVALID_ARGUMENT, "equality_penalty_rho must be in [0, 1)");
+  if (!(prm->max_lambda >= 0) || !(prm->min_lambda <= prm->max_lambda)) return fail(MO_ERR_INVALID_ARGUMENT, "need 0 <= min_lambda <= max_lambda");
+  if (!(prm->lambda_initial >= prm->min_lambda) || !(prm->lambda_initial <= prm->max_lambda)) return fail(MO_ERR_INVALID_ARGUMENT, "lambda_initial outside [min_lambda, max_lambda]");
+  if (!(prm->lambda_failure_init >= 0)) return fail(MO_ERR_INVALID_ARGUMENT, "lambda_failure_init must be >= 0");
+  if (!(prm->lambda_decrease_on_success >= 0) || !(prm->lambda_decrease_on_success < 1.0)) return fail(MO_ERR_INVALID_ARGUMENT, "lambda_decrease_on_success must be in [0, 1)");
+  if (!(prm->lambda_decrease_on_restore >= 0) || !(prm->lambda_decrease_on_restore < 1.0)) return fail(MO_ERR_INVALID_ARGUMENT, "lambda_decrease_on_restore must be in [0, 1)");
+  if (prm->line_search_strategy != MO_ARMIJO_BACKTRACK && prm->line_search_strategy != MO_POLYNOMIAL_APPROXIMATION)
+    return fail(MO_ERR_INVALID_ARGUMENT, "bad line_search_strategy");
+  if (!np->vars || !np->candidate || !np->J || !np->r || !np->r_cand) return fail(MO_ERR_INVALID_ARGUMENT, "vars / candidate / J / r / r_cand is NULL");
+  if (d.k > 0 && (!np->J_eq || !np->r_eq || !np->r_eq_cand)) return fail(MO_ERR_DIMENSION, "k = %d but J_eq / r_eq / r_eq_cand is NULL", d.k);
+  if (d.m > 0 && (!np->cons_var || !np->cons_a || !np->cons_b)) return fail(MO_ERR_INVALID_ARGUMENT, "m = %d but constraint arrays are NULL", d.m);
+  if (!termination) return fail(MO_ERR_INVALID_ARGUMENT, "termination is NULL");
+  if (batch == 0) return MO_OK;
+  MO_HIP_CHECK(hipSetDevice(d.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int n = d.n, k = d.k, m = d.m;
+  const long long V = n + 2 * m + k, Vs = (V + 1) & ~1ll;  // even stride: the fused kernels want 16-byte aligned states
+
+  NlsScratch scratch;
+  double *qp_vars, *cons_b, *cons_a, *errors_pre, *errors_step, *deriv, *quad, *lagrange, *sd;
+  int *qp_status, *qp_term, *qp_nit, *si, *counters, *cons_var;
+  MO_HIP_CHECK(scratch.alloc(&qp_vars, (size_t)batch * Vs));
+  MO_HIP_CHECK(scratch.alloc(&cons_b, (size_t)batch * m));  // the QP's constraints: one stride for (variable, a, shifted b)
+  MO_HIP_CHECK(scratch.alloc(&cons_a, (size_t)batch * m));
+  MO_HIP_CHECK(scratch.alloc(&cons_var, (size_t)batch * m));
+  MO_HIP_CHECK(scratch.alloc(&errors_pre, (size_t)batch * 2));
+  MO_HIP_CHECK(scratch.alloc(&errors_step, (size_t)batch * 2));
+  MO_HIP_CHECK(scratch.alloc(&deriv, (size_t)batch * 2));
+  MO_HIP_CHECK(scratch.alloc(&quad, (size_t)batch));
+  MO_HIP_CHECK(scratch.alloc(&lagrange, (size_t)batch * 2));
+  MO_HIP_CHECK(scratch.alloc(&sd, (size_t)batch * mo::NLS_SD));
+  MO_HIP_CHECK(scratch.alloc(&qp_status, (size_t)batch));
+  MO_HIP_CHECK(scratch.alloc(&qp_term, (size_t)batch));
+  MO_HIP_CHECK(scratch.alloc(&qp_nit, (size_t)batch));
+  MO_HIP_CHECK(scratch.alloc(&si, (size_t)batch * mo::NLS_SI));
+  MO_HIP_CHECK(scratch.alloc(&counters, 2));
+
+  mo::NlsArgs na;
+  memset(&na, 0, sizeof(na));
+  na.n = n; na.k = k; na.m = m; na.batch = batch; na.prm = *prm;
+  na.vars = (double*)np->vars; na.vars_stride = np->vars_stride;
+  na.cand = (double*)np->candidate; na.cand_stride = np->candidate_stride;
+  na.qp_vars = qp_vars; na.qp_vars_stride = Vs;
+  na.errors_pre = errors_pre; na.errors_step = errors_step; na.deriv = deriv; na.quad = quad; na.lagrange = lagrange;
+  na.qp_status = qp_status; na.qp_term = qp_term; na.qp_nit = qp_nit;
+  na.sd = sd; na.si = si;
+  na.iterations = (double*)iterations; na.rec = MO_NLS_ITER_RECORD(prm->max_line_search_iterations);
+  na.termination = termination; na.num_iterations = num_iterations; na.status = status;
+  na.counters = counters;
+  MO_HIP_CHECK(mo::launch_nls_init(na, s));
+  if (prm->max_iterations == 0) {  // nonlinear.cc:97, 157: no iteration at all
+    MO_HIP_CHECK(hipMemsetAsync(termination, 0, sizeof(int32_t) * (size_t)batch, s));
+    if (num_iterations) MO_HIP_CHECK(hipMemsetAsync(num_iterations, 0, sizeof(int32_t) * (size_t)batch, s));
+    return MO_OK;
+  }
+
+  // the QP of this outer iteration (LinearizeAndFillQP's output, nonlinear.cc:98) in J-level form
+  mo_problem qp;
+  memset(&qp, 0, sizeof(qp));
+  qp.J = np->J; qp.J_stride = np->J_stride; qp.J_ld = np->J_ld; qp.J_layout = np->J_layout;
+  qp.r = np->r; qp.r_stride = np->r_stride;
+  qp.lambda_vec = sd + mo::NLS_SD_LAMBDA; qp.lambda_stride = mo::NLS_SD;
+  qp.A_eq = np->J_eq; qp.A_stride = np->J_eq_stride; qp.A_ld = np->J_eq_ld;
+  qp.b_eq = np->r_eq; qp.b_stride = np->r_eq_stride;
+  qp.cons_var = cons_var; qp.cons_a = cons_a; qp.cons_b = cons_b; qp.cons_stride = m;
+  mo_solve_params sp;
+  mo_default_solve_params(&sp);       // ComputeStepDirection, nonlinear.cc:226-241
+  sp.max_iterations = prm->max_qp_iterations;
+  sp.termination_kkt_tol = prm->termination_kkt_tolerance;
+  sp.initial_mu = 1.0;
+  sp.sigma = 0.1;
+  sp.initialize_mu_with_complementarity = 0;
+  sp.initial_guess_method = k > 0 ? MO_GUESS_SOLVE_EQUALITY_CONSTRAINED : MO_GUESS_NAIVE;
+
+  mo::AuxArgs ea;  // errors at the linearisation point / at the candidate
+  memset(&ea, 0, sizeof(ea));
+  ea.n = n; ea.k = k; ea.m = m; ea.m_r = d.m_r; ea.batch = batch;
+  mo::AuxArgs sa = ea;  // ShiftTo
+  sa.x = np->vars; sa.x_stride = np->vars_stride;
+  sa.cons_var = np->cons_var; sa.cons_a = np->cons_a; sa.cons_b = np->cons_b; sa.cons_stride = np->cons_stride;
+  sa.cons_b_out = cons_b; sa.cons_b_out_stride = m; sa.cons_var_out = cons_var; sa.cons_a_out = cons_a;
+  mo::AuxArgs da = ea;  // ComputeQPCostDerivative
+  da.x = qp_vars; da.x_stride = Vs;
+  da.J = np->J; da.J_stride = np->J_stride; da.J_ld = np->J_ld; da.J_row_major = np->J_layout == MO_ROW_MAJOR;
+  da.r = np->r; da.r_stride = np->r_stride;
+  da.A = np->J_eq; da.A_stride = np->J_eq_stride; da.A_ld = np->J_eq_ld; da.b = np->r_eq; da.b_stride = np->r_eq_stride;
+  da.lambda_vec = sd + mo::NLS_SD_LAMBDA; da.lambda_vec_stride = mo::NLS_SD;
+  da.out2 = deriv; da.quad_out = quad;
+
+  int host_counters[2];
+  for (int iter = 0; iter < prm->max_iterations; ++iter) {
+    na.iter = iter;
+    if (eval(user, MO_NLS_EVAL_LINEARIZE, stream) != 0) return fail(MO_ERR_CALLBACK, "eval(LINEARIZE) failed at iteration %d", iter);
+    // errors_pre (nonlinear.cc:184-186, 203) and the shifted constraints (:209-212)
+    ea.r = np->r; ea.r_stride = np->r_stride; ea.b = np->r_eq; ea.b_stride = np->r_eq_stride; ea.out2 = errors_pre;
+    MO_HIP_CHECK(mo::launch_nonlinear_errors(ea, d.dtype, s));
+    if (m > 0) MO_HIP_CHECK(mo::launch_shift_constraints(sa, d.dtype, s));
+    // ComputeStepDirection (nonlinear.cc:216-247): the interior-point QP on device
+    if (int rc = mo_qp_solve(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, nullptr, lagrange, qp_status, stream)) return rc;
+    MO_HIP_CHECK(mo::launch_cost_derivative(da, d.dtype, s));
+    MO_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
+    MO_HIP_CHECK(mo::launch_nls_begin_search(na, s));
+    // SelectStepSize (nonlinear.cc:346-412)
+    for (int ls = 0; ls <= prm->max_line_search_iterations; ++ls) {
+      MO_HIP_CHECK(hipMemcpyAsync(host_counters, counters, sizeof(int), hipMemcpyDeviceToHost, s));
+      MO_HIP_CHECK(hipStreamSynchronize(s));
+      if (host_counters[0] == 0) break;  // nobody is searching any more
+      na.ls = ls;
+      if (eval(user, MO_NLS_EVAL_ERRORS, stream) != 0) return fail(MO_ERR_CALLBACK, "eval(ERRORS) failed at iteration %d", iter);
+      ea.r = np->r_cand; ea.r_stride = np->r_cand_stride; ea.b = np->r_eq_cand; ea.b_stride = np->r_eq_cand_stride; ea.out2 = errors_step;
+      MO_HIP_CHECK(mo::launch_nonlinear_errors(ea, d.dtype, s));
+      MO_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int), s));
+      MO_HIP_CHECK(mo::launch_nls_search_step(na, s));
+    }
+    MO_HIP_CHECK(mo::launch_nls_update(na, s));
+    MO_HIP_CHECK(hipMemcpyAsync(host_counters, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    MO_HIP_CHECK(hipStreamSynchronize(s));
+    if (host_counters[1] == 0) break;  // every problem has terminated
+  }
+  MO_HIP_CHECK(hipStreamSynchronize(s));  // the scratch is released on return
+  return MO_OK;
 }
 
 }  // extern "C"

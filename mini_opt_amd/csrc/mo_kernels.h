@@ -79,6 +79,7 @@ struct AuxArgs {
   const int* cons_var; const void* cons_a; const void* cons_b; long long cons_stride;
   double lambda; const void* lambda_vec; long long lambda_vec_stride;
   void* cons_b_out; long long cons_b_out_stride;
+  int* cons_var_out; void* cons_a_out;                // optional per-problem copies of (variable, a), same stride as cons_b_out
   void* out2;                                         // [batch][2]
   void* quad_out;                                     // [batch]
   int* status;
@@ -86,5 +87,32 @@ struct AuxArgs {
 hipError_t launch_shift_constraints(const AuxArgs& a, int dtype, hipStream_t stream);
 hipError_t launch_nonlinear_errors(const AuxArgs& a, int dtype, hipStream_t stream);
 hipError_t launch_cost_derivative(const AuxArgs& a, int dtype, hipStream_t stream);
+
+// per-problem state machine of the batched SQP loop (mo_nls_solve), nls_kernels.hip; fp64 only
+enum { NLS_SD_LAMBDA = 0, NLS_SD_PENALTY, NLS_SD_ALPHA, NLS_SD_DIRECTIONAL, NLS_SD_A2, NLS_SD_T2, NLS_SD_A1, NLS_SD_T1, NLS_SD = 8 };
+enum { NLS_SI_TERM = 0, NLS_SI_STATE, NLS_SI_LS_RESULT, NLS_SI_NSTEPS, NLS_SI_NITER, NLS_SI = 8 };
+struct NlsArgs {
+  int n, k, m;
+  long long batch;
+  mo_nls_params prm;
+  int iter, ls;                                    // outer / line-search iteration this launch belongs to
+  double* vars; long long vars_stride;
+  double* cand; long long cand_stride;
+  const double* qp_vars; long long qp_vars_stride;  // [x | s | y | z] of the QP; dx = its x block
+  const double* errors_pre;                         // [batch][2]
+  const double* errors_step;                        // [batch][2]
+  const double* deriv;                              // [batch][2]
+  const double* quad;                               // [batch]
+  const double* lagrange;                           // [batch][2]
+  const int* qp_status; const int* qp_term; const int* qp_nit;
+  double* sd; int* si;                              // [batch][NLS_SD], [batch][NLS_SI]
+  double* iterations; int rec;                      // [batch][max_iterations][rec] or NULL
+  int* termination; int* num_iterations; int* status;
+  int* counters;                                    // [0] problems still in the line search, [1] problems still active
+};
+hipError_t launch_nls_init(const NlsArgs& a, hipStream_t stream);
+hipError_t launch_nls_begin_search(const NlsArgs& a, hipStream_t stream);
+hipError_t launch_nls_search_step(const NlsArgs& a, hipStream_t stream);
+hipError_t launch_nls_update(const NlsArgs& a, hipStream_t stream);
 
 }  // namespace mo

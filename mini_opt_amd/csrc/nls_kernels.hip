@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void shift_constraints_kernel(const AuxArgs a)
     const bool ok = v >= 0 && v < a.n;
     bad = bad || !ok;
     ((T*)a.cons_b_out)[p * a.cons_b_out_stride + i] = ok ? ca * x[v] + cb : (T)__builtin_nan("");  // qp.hpp:57-59
+    if (a.cons_var_out) a.cons_var_out[p * a.cons_b_out_stride + i] = v;
+    if (a.cons_a_out) ((T*)a.cons_a_out)[p * a.cons_b_out_stride + i] = ca;
   }
   T l1 = 0;
   for (int i = lane; i < a.k; i += 64) l1 += fabs(((const T*)a.b)[p * a.b_stride + i]);                  // nonlinear.cc:203
@@ -118,6 +120,173 @@ __global__ __launch_bounds__(256) void cost_derivative_kernel(const AuxArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The per-problem state machine of ConstrainedNonlinearLeastSquares::Solve (nonlinear.cc:75-158) for mo_nls_solve.
+// One wavefront per problem: lane 0 takes the scalar decisions, all lanes move the n-vectors.
+__device__ inline double total_of(const double* e, double penalty) { return e[0] + penalty * e[1]; }  // Errors::Total, structs.hpp:177
+
+__global__ __launch_bounds__(256) void nls_init_kernel(const NlsArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.batch) return;
+  double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
+  sd[NLS_SD_LAMBDA] = a.prm.lambda_initial;              // nonlinear.cc:92
+  sd[NLS_SD_PENALTY] = a.prm.equality_penalty_initial;   // nonlinear.cc:93
+  si[NLS_SI_TERM] = -1; si[NLS_SI_STATE] = 0; si[NLS_SI_LS_RESULT] = -1; si[NLS_SI_NSTEPS] = 0; si[NLS_SI_NITER] = 0;
+  if (a.status) a.status[p] = MO_STATUS_OK;
+}
+
+// After the QP: penalty (nonlinear.cc:108-115, 485-500), directional derivative, first trial point alpha = 1 (:363, :160-168)
+__global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= a.batch) return;
+  double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
+  if (si[NLS_SI_TERM] >= 0) return;  // wave-uniform
+  const int qp_status = a.qp_status[p];
+  double* rec = a.iterations ? a.iterations + ((size_t)p * a.prm.max_iterations + a.iter) * a.rec : nullptr;
+  const double* e0 = a.errors_pre + 2 * p;
+  const double d_f = a.deriv[2 * p], d_eq = a.deriv[2 * p + 1];
+  double penalty = sd[NLS_SD_PENALTY];
+  if (qp_status == MO_STATUS_OK && a.k > 0) {
+    double new_penalty;
+    if (a.m == 0) {  // the reference runs QPNullSpaceSolver here and has no multipliers: inequality (18.36), nonlinear.cc:491-499
+      const double l1 = fmax(e0[1], 2.220446049250313e-16);
+      const double q = d_f + 0.5 * fmax(0.0, a.quad[p]);
+      new_penalty = q / ((1.0 - a.prm.equality_penalty_rho) * l1);
+    } else {
+      new_penalty = a.lagrange[2 * p + 1];                 // l_infinity of y, nonlinear.cc:488-490
+    }
+    if (new_penalty > penalty) penalty = new_penalty * a.prm.equality_penalty_scale_factor;
+  }
+  if (lane == 0) {
+    if (rec) {
+      for (int i = 0; i < a.rec; ++i) rec[i] = __builtin_nan("");
+      rec[1] = sd[NLS_SD_LAMBDA]; rec[2] = e0[0]; rec[3] = e0[1]; rec[4] = d_f; rec[5] = d_eq; rec[6] = penalty;
+      rec[8] = 0; rec[9] = a.qp_term[p]; rec[10] = a.qp_nit[p]; rec[11] = qp_status;
+    }
+    if (qp_status != MO_STATUS_OK) {                       // the reference throws here (qp.cc:285, 303-307)
+      si[NLS_SI_TERM] = MO_NLS_QP_FAILURE;
+      si[NLS_SI_NITER] = a.iter + 1;
+      if (a.status) a.status[p] = qp_status;
+      if (rec) rec[0] = si[NLS_SI_STATE];
+    } else {
+      sd[NLS_SD_PENALTY] = penalty;
+      sd[NLS_SD_DIRECTIONAL] = d_f + penalty * d_eq;       // DirectionalDerivatives::Total, structs.hpp:197
+      sd[NLS_SD_ALPHA] = 1.0;
+      si[NLS_SI_LS_RESULT] = -1; si[NLS_SI_NSTEPS] = 0;
+      atomicAdd(a.counters, 1);
+    }
+  }
+  if (qp_status != MO_STATUS_OK) return;
+  const double* x = a.vars + p * a.vars_stride; const double* dx = a.qp_vars + p * a.qp_vars_stride;
+  double* c = a.cand + p * a.cand_stride;
+  for (int i = lane; i < a.n; i += 64) c[i] = x[i] + dx[i] * 1.0;
+}
+
+// One evaluation of the line search (nonlinear.cc:378-407) and, if it goes on, the next alpha (:364-376, 414-438)
+__global__ __launch_bounds__(256) void nls_search_step_kernel(const NlsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= a.batch) return;
+  double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
+  if (si[NLS_SI_TERM] >= 0 || si[NLS_SI_LS_RESULT] >= 0) return;
+  const double* e0 = a.errors_pre + 2 * p; const double* e1 = a.errors_step + 2 * p;
+  const double penalty = sd[NLS_SD_PENALTY], directional = sd[NLS_SD_DIRECTIONAL], alpha = sd[NLS_SD_ALPHA];
+  const double d_f = a.deriv[2 * p], d_eq = a.deriv[2 * p + 1];
+  const double phi0 = total_of(e0, penalty), phi1 = total_of(e1, penalty);
+  int result = -1;
+  double next_alpha = alpha;
+  const bool finite = isfinite(e1[0]) && isfinite(e1[1]);
+  if (!finite) result = MO_LS_FAILURE_NON_FINITE_COST;                                            // :383-385
+  else if (fmax(fabs(d_f), fabs(d_eq)) < a.prm.absolute_first_derivative_tol) result = MO_LS_FIRST_ORDER_SATISFIED;  // :387-389
+  else if (directional > 0) result = MO_LS_POSITIVE_DERIVATIVE;                                   // :390-393
+  else if (phi1 <= phi0 + directional * alpha * 1.0e-4) result = MO_LS_SUCCESS;                   // armijo_c1, :118, :396-400
+  else if (a.ls >= a.prm.max_line_search_iterations) result = MO_LS_MAX_ITERATIONS;               // :403
+  else if (a.prm.line_search_strategy == MO_POLYNOMIAL_APPROXIMATION) {
+    bool valid = true;
+    if (a.ls == 0) {                                       // QuadraticApproxMinimum, :524-531
+      const double numerator = phi1 - directional * alpha - phi0;
+      if (directional > 0 || numerator <= 0) valid = false;
+      else next_alpha = -directional * alpha * alpha / (2.0 * numerator);
+    } else {                                               // CubicApproxCoeffs + CubicApproxMinimum, :558-603
+      const double a0 = sd[NLS_SD_A1], t0 = sd[NLS_SD_T1];  // second last step
+      const double a1 = alpha, t1 = phi1;                    // last step
+      const double m00 = a0 * a0 * a0, m01 = a0 * a0, m10 = a1 * a1 * a1, m11 = a1 * a1;
+      const double r0 = t0 - phi0 - directional * a0, r1 = t1 - phi0 - directional * a1;
+      const double det = m00 * m11 - m01 * m10;
+      const double ca = (m11 * r0 - m01 * r1) / det, cb = (-m10 * r0 + m00 * r1) / det;
+      const double arg = cb * cb - 3 * ca * directional;
+      if (ca == 0.0 || arg < -1.0e-12) valid = false;
+      else next_alpha = (-cb + sqrt(fmax(arg, 0.0))) / (3 * ca);
+    }
+    if (!valid || !isfinite(next_alpha) || next_alpha <= 0.0 || next_alpha >= alpha) result = MO_LS_FAILURE_INVALID_ALPHA;  // :369-372
+  } else {
+    next_alpha = alpha * a.prm.armijo_search_tau;          // :377-380
+  }
+  if (lane == 0) {
+    const int ns = si[NLS_SI_NSTEPS];
+    if (a.iterations) {
+      double* rec = a.iterations + ((size_t)p * a.prm.max_iterations + a.iter) * a.rec;
+      rec[MO_NLS_ITER_HEADER + 3 * ns] = alpha; rec[MO_NLS_ITER_HEADER + 3 * ns + 1] = e1[0]; rec[MO_NLS_ITER_HEADER + 3 * ns + 2] = e1[1];
+    }
+    si[NLS_SI_NSTEPS] = ns + 1;
+    sd[NLS_SD_A2] = sd[NLS_SD_A1]; sd[NLS_SD_T2] = sd[NLS_SD_T1];
+    sd[NLS_SD_A1] = alpha; sd[NLS_SD_T1] = phi1;
+    if (result >= 0) si[NLS_SI_LS_RESULT] = result;
+    else { sd[NLS_SD_ALPHA] = next_alpha; atomicAdd(a.counters, 1); }
+  }
+  if (result >= 0) return;
+  const double* x = a.vars + p * a.vars_stride; const double* dx = a.qp_vars + p * a.qp_vars_stride;
+  double* c = a.cand + p * a.cand_stride;
+  for (int i = lane; i < a.n; i += 64) c[i] = x[i] + dx[i] * next_alpha;                          // RetractCandidateVars, :160-168
+}
+
+// UpdateLambdaAndCheckExitConditions (nonlinear.cc:296-339) + the bookkeeping of the outer loop (:121-157)
+__global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= a.batch) return;
+  double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
+  const bool was_active = si[NLS_SI_TERM] < 0;
+  if (was_active) {
+    const int result = si[NLS_SI_LS_RESULT];
+    const double* e0 = a.errors_pre + 2 * p;
+    const double penalty = sd[NLS_SD_PENALTY];
+    double lambda = sd[NLS_SD_LAMBDA];
+    int state = si[NLS_SI_STATE], term = -1;
+    if (result == MO_LS_SUCCESS) {
+      double* x = a.vars + p * a.vars_stride; const double* c = a.cand + p * a.cand_stride;
+      for (int i = lane; i < a.n; i += 64) x[i] = c[i];                                            // variables_.swap(candidate_vars_), :303
+      lambda = fmax(lambda * (state == 1 ? a.prm.lambda_decrease_on_restore : a.prm.lambda_decrease_on_success), a.prm.min_lambda);
+      state = 0;
+      const double* e1 = a.errors_step + 2 * p;            // the accepted step is the last one evaluated
+      if (fmax(e1[0], e1[1]) < a.prm.absolute_exit_tol) term = MO_NLS_SATISFIED_ABSOLUTE_TOL;      // :314-316
+      else if (total_of(e1, penalty) > total_of(e0, penalty) * (1 - a.prm.relative_exit_tol)) term = MO_NLS_SATISFIED_RELATIVE_TOL;
+    } else if (result == MO_LS_FIRST_ORDER_SATISFIED) {
+      term = MO_NLS_SATISFIED_FIRST_ORDER_TOL;                                                    // :321-323
+    } else if (result == MO_LS_MAX_ITERATIONS || result == MO_LS_POSITIVE_DERIVATIVE) {
+      if (state == 0) { lambda = fmax(a.prm.lambda_failure_init, lambda * 10.0); state = 1; }     // :326-329
+      else lambda *= 10.0;                                                                        // :332
+      if (lambda > a.prm.max_lambda) term = MO_NLS_MAX_LAMBDA;                                    // :334-337
+    }
+    if (lane == 0) {
+      sd[NLS_SD_LAMBDA] = lambda; si[NLS_SI_STATE] = state; si[NLS_SI_NITER] = a.iter + 1;
+      if (a.iterations) {
+        double* rec = a.iterations + ((size_t)p * a.prm.max_iterations + a.iter) * a.rec;
+        rec[0] = state; rec[7] = result; rec[8] = si[NLS_SI_NSTEPS];
+      }
+      if (term >= 0) si[NLS_SI_TERM] = term;
+      else atomicAdd(a.counters + 1, 1);
+    }
+  }
+  if (lane == 0) {
+    const int t = si[NLS_SI_TERM];
+    if (a.termination) a.termination[p] = t >= 0 ? t : MO_NLS_MAX_ITERATIONS;                     // :157
+    if (a.num_iterations) a.num_iterations[p] = si[NLS_SI_NITER];
+  }
+}
+
 template <typename K64, typename K32>
 hipError_t launch_aux(K64 k64, K32 k32, const AuxArgs& a, int dtype, hipStream_t stream) {
   if (a.batch <= 0) return hipSuccess;
@@ -137,6 +306,23 @@ hipError_t launch_nonlinear_errors(const AuxArgs& a, int dtype, hipStream_t stre
 }
 hipError_t launch_cost_derivative(const AuxArgs& a, int dtype, hipStream_t stream) {
   return launch_aux(cost_derivative_kernel<double>, cost_derivative_kernel<float>, a, dtype, stream);
+}
+
+hipError_t launch_nls_init(const NlsArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(nls_init_kernel, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_nls_begin_search(const NlsArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(nls_begin_search_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_nls_search_step(const NlsArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(nls_search_step_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_nls_update(const NlsArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(nls_update_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  return hipGetLastError();
 }
 
 }  // namespace mo

@@ -1,0 +1,252 @@
+"""Host-side (Python) mirror of mini_opt's constrained nonlinear least squares for BATCHES of problems on one MI355X.
+
+    reference (C++)                                              here
+    ---------------------------------------------------------    ------------------------------------------------------
+    mini_opt::Problem                      nonlinear.hpp:33-52    Problem (dimension, cost, equality, inequality_constraints)
+    ConstrainedNonlinearLeastSquares       nonlinear.hpp:127-230  ConstrainedNonlinearLeastSquares (Solve / variables /
+      ::Params                             nonlinear.hpp:64-124     EvaluateNonlinearErrors), Params (same names, defaults)
+      ::LinearizeAndFillQP (static)        nonlinear.cc:170-214   fill_qp
+      ::ComputeQPCostDerivative (static)   nonlinear.cc:452-483   qp_cost_derivative
+    NLSSolverOutputs / NLSIteration        structs.hpp:277-347    NLSSolverOutputs (tensors, one row per problem)
+
+The residual functions are the caller's (the reference's Residual objects are host functors, residual.hpp:28-143): here they
+are callables on torch batches, cost(x [B, n], want_J) -> (r [B, m_r], J [B, m_r, n] | None) and equality(...) ->
+(r_eq [B, k], J_eq [B, k, n] | None), enqueuing device work on the current stream.  Everything else runs in the HIP library
+behind mo_nls_solve (include/mini_opt_hip.h); there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .qp import BatchedQP, _DT, _ptr, _stream
+
+# NLSTerminationState (structs.hpp:233-248) + MO_NLS_QP_FAILURE (the reference throws there)
+(MAX_ITERATIONS, SATISFIED_ABSOLUTE_TOL, SATISFIED_RELATIVE_TOL, SATISFIED_FIRST_ORDER_TOL, MAX_LAMBDA, QP_INDEFINITE,
+ USER_CALLBACK, QP_FAILURE) = range(8)
+# StepSizeSelectionResult (structs.hpp:215-228)
+(STEP_SUCCESS, STEP_MAX_ITERATIONS, STEP_FIRST_ORDER_SATISFIED, STEP_POSITIVE_DERIVATIVE, STEP_FAILURE_NON_FINITE_COST,
+ STEP_FAILURE_INVALID_ALPHA) = range(6)
+ARMIJO_BACKTRACK, POLYNOMIAL_APPROXIMATION = 0, 1  # LineSearchStrategy (structs.hpp:148-153)
+
+
+def TerminationStateIndicatesSatisfiedTol(state) -> torch.Tensor:
+    """structs.hpp:250-262, element-wise."""
+    return (state == SATISFIED_ABSOLUTE_TOL) | (state == SATISFIED_RELATIVE_TOL) | (state == SATISFIED_FIRST_ORDER_TOL)
+
+
+@dataclass
+class Params:
+    """ConstrainedNonlinearLeastSquares::Params, nonlinear.hpp:64-124 (same names, same defaults)."""
+    max_iterations: int = 10
+    max_qp_iterations: int = 10
+    termination_kkt_tolerance: float = 1.0e-6
+    absolute_exit_tol: float = 1.0e-12
+    relative_exit_tol: float = 1.0e-5
+    absolute_first_derivative_tol: float = 1.0e-6
+    max_line_search_iterations: int = 2
+    line_search_strategy: int = POLYNOMIAL_APPROXIMATION
+    armijo_search_tau: float = 0.8
+    equality_penalty_initial: float = 1.0
+    equality_penalty_scale_factor: float = 1.01
+    equality_penalty_rho: float = 0.1
+    lambda_initial: float = 0.0
+    lambda_failure_init: float = 1.0e-2
+    lambda_decrease_on_success: float = 0.1
+    lambda_decrease_on_restore: float = 0.8
+    max_lambda: float = 1.0
+    min_lambda: float = 0.0
+
+    def as_struct(self) -> L.NlsParams:
+        p = L.NlsParams()
+        L.lib().mo_default_nls_params(C.byref(p))
+        for name, _ in L.NlsParams._fields_:
+            setattr(p, name, getattr(self, name))
+        return p
+
+
+ResidualFn = Callable[[torch.Tensor, bool], Tuple[torch.Tensor, Optional[torch.Tensor]]]
+
+
+@dataclass
+class Problem:
+    """mini_opt::Problem (nonlinear.hpp:33-52) for a batch of independent problems sharing one structure."""
+    dimension: int
+    cost: ResidualFn
+    cost_rows: int                                  # m_r: stacked rows of all cost residuals
+    equality: Optional[ResidualFn] = None
+    equality_rows: int = 0                          # k
+    inequality_constraints: Sequence[Tuple[int, float, float]] = field(default_factory=list)  # (variable, a, b): a x + b >= 0
+
+
+@dataclass
+class NLSSolverOutputs:
+    """NLSSolverOutputs (structs.hpp:332-347), one row per problem."""
+    termination_state: torch.Tensor  # [B] int32
+    num_iterations: torch.Tensor     # [B] int32
+    iterations: torch.Tensor         # [B, max_iterations, 12 + 3 (max_line_search_iterations + 1)] NLSIteration records
+    status: torch.Tensor             # [B] int32 QP status of a problem that ended with QP_FAILURE
+
+    def NumQPIterations(self) -> torch.Tensor:
+        it = torch.nan_to_num(self.iterations[:, :, 10], nan=0.0)
+        return it.sum(dim=1).to(torch.int64)
+
+    def NumLineSearchSteps(self) -> torch.Tensor:
+        return torch.nan_to_num(self.iterations[:, :, 8], nan=0.0).sum(dim=1).to(torch.int64)
+
+    def NumFailedLineSearches(self) -> torch.Tensor:
+        r = self.iterations[:, :, 7]
+        return ((r == STEP_MAX_ITERATIONS) | (r == STEP_POSITIVE_DERIVATIVE)).sum(dim=1)
+
+
+class _Plan:
+    def __init__(self, n, k, m, m_r, dtype, device, batch):
+        desc = L.PlanDesc(n, k, m, m_r, _DT[dtype], device.index or 0, 0, 0, batch)
+        self.h = C.c_void_p()
+        L.check(L.lib().mo_plan_create(C.byref(desc), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            L.lib().mo_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+class ConstrainedNonlinearLeastSquares:
+    """Batched mirror of mini_opt::ConstrainedNonlinearLeastSquares (nonlinear.hpp:127-230)."""
+
+    def __init__(self, problem: Problem, batch: int, device=None, dtype=torch.float64):
+        if problem is None:
+            raise L.MiniOptError(-1, "Must have a valid problem")          # F_ASSERT nonlinear.cc:78
+        if dtype != torch.float64:
+            raise L.MiniOptError(-3, "mo_nls_solve needs fp64")
+        self.p_ = problem
+        self.batch = int(batch)
+        dev = torch.device(device if device is not None else "cuda:0")
+        n, k, m, m_r = problem.dimension, problem.equality_rows, len(problem.inequality_constraints), problem.cost_rows
+        self.n, self.k, self.m, self.m_r = n, k, m, m_r
+        self._plan = _Plan(n, k, m, m_r, dtype, dev, self.batch)
+        z = lambda *shape, dt=dtype: torch.zeros(*shape, dtype=dt, device=dev)
+        B = self.batch
+        self.variables_ = z(B, n)
+        self.candidate_vars_ = z(B, n)
+        self.J, self.r, self.r_cand = z(B, m_r, n), z(B, m_r), z(B, m_r)
+        self.J_eq, self.r_eq, self.r_eq_cand = (z(B, n, k), z(B, k), z(B, k)) if k else (None, None, None)   # J_eq: k x n col-major
+        if m:
+            self.cons_var = torch.tensor([[c[0] for c in problem.inequality_constraints]], dtype=torch.int32, device=dev)
+            self.cons_a = torch.tensor([[c[1] for c in problem.inequality_constraints]], dtype=dtype, device=dev)
+            self.cons_b = torch.tensor([[c[2] for c in problem.inequality_constraints]], dtype=dtype, device=dev)
+        else:
+            self.cons_var = self.cons_a = self.cons_b = None
+
+    # ---- callbacks: enqueue the user's residual evaluation on the stream the library works on
+    def _eval(self, user, what, stream):
+        try:
+            if what == L.MO_NLS_EVAL_LINEARIZE:
+                r, J = self.p_.cost(self.variables_, True)
+                self.r.copy_(r); self.J.copy_(J)
+                if self.k:
+                    r_eq, J_eq = self.p_.equality(self.variables_, True)
+                    self.r_eq.copy_(r_eq); self.J_eq.copy_(J_eq.transpose(1, 2))
+            else:
+                r, _ = self.p_.cost(self.candidate_vars_, False)
+                self.r_cand.copy_(r)
+                if self.k:
+                    r_eq, _ = self.p_.equality(self.candidate_vars_, False)
+                    self.r_eq_cand.copy_(r_eq)
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            self._callback_error = e
+            return 1
+
+    def _problem_struct(self) -> L.NlsProblem:
+        n, k, m, m_r = self.n, self.k, self.m, self.m_r
+        p = L.NlsProblem()
+        p.vars, p.vars_stride = _ptr(self.variables_), n
+        p.candidate, p.candidate_stride = _ptr(self.candidate_vars_), n
+        p.J, p.J_stride, p.J_ld, p.J_layout = _ptr(self.J), m_r * n, n, L.MO_ROW_MAJOR
+        p.r, p.r_stride = _ptr(self.r), m_r
+        p.r_cand, p.r_cand_stride = _ptr(self.r_cand), m_r
+        if k:
+            p.J_eq, p.J_eq_stride, p.J_eq_ld = _ptr(self.J_eq), n * k, k
+            p.r_eq, p.r_eq_stride = _ptr(self.r_eq), k
+            p.r_eq_cand, p.r_eq_cand_stride = _ptr(self.r_eq_cand), k
+        if m:
+            p.cons_var, p.cons_a, p.cons_b, p.cons_stride = _ptr(self.cons_var), _ptr(self.cons_a), _ptr(self.cons_b), 0
+        return p
+
+    def Solve(self, params: Params, variables: torch.Tensor) -> NLSSolverOutputs:
+        """nonlinear.cc:75-158 for every problem of the batch."""
+        if tuple(variables.shape) != (self.batch, self.n):
+            raise L.MiniOptError(-2, f"variables must be [{self.batch}, {self.n}]")
+        self.variables_.copy_(variables)
+        dev = self.variables_.device
+        B = self.batch
+        rec = L.MO_NLS_ITER_HEADER + 3 * (params.max_line_search_iterations + 1)
+        term = torch.zeros(B, dtype=torch.int32, device=dev)
+        nit = torch.zeros(B, dtype=torch.int32, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        its = torch.full((B, max(params.max_iterations, 1), rec), float("nan"), dtype=torch.float64, device=dev)
+        sp = params.as_struct()
+        prob = self._problem_struct()
+        self._callback_error = None
+        cb = L.NLS_EVAL_FN(self._eval)
+        rc = L.lib().mo_nls_solve(self._plan.h, C.byref(prob), B, C.byref(sp), cb, None, _ptr(term), _ptr(nit), _ptr(its),
+                                  _ptr(status), _stream())
+        if self._callback_error is not None:
+            raise self._callback_error
+        L.check(rc)
+        return NLSSolverOutputs(term, nit, its, status)
+
+    def variables(self) -> torch.Tensor:
+        return self.variables_
+
+    def EvaluateNonlinearErrors(self, vars_: torch.Tensor) -> torch.Tensor:
+        """nonlinear.cc:279-293: [B, 2] = {f, equality}."""
+        r, _ = self.p_.cost(vars_, False)
+        r_eq = self.p_.equality(vars_, False)[0] if self.k else None
+        return nonlinear_errors(self._plan, r.contiguous(), None if r_eq is None else r_eq.contiguous())
+
+
+# ---- the static pieces, usable on their own ----------------------------------------------------------------------
+def nonlinear_errors(plan: _Plan, r: torch.Tensor, r_eq: Optional[torch.Tensor]) -> torch.Tensor:
+    B = int(r.shape[0])
+    out = torch.empty(B, 2, dtype=r.dtype, device=r.device)
+    L.check(L.lib().mo_nonlinear_errors(plan.h, _ptr(r), int(r.shape[1]), _ptr(r_eq), 0 if r_eq is None else int(r_eq.shape[1]),
+                                        B, _ptr(out), _stream()))
+    return out
+
+
+def fill_qp(problem: BatchedQP, x: torch.Tensor):
+    """LinearizeAndFillQP (nonlinear.cc:170-214) for dense stacks: `problem` carries (J, r, lam), the equality stack as
+    (A_eq, b_eq) and the UNSHIFTED constraints.  Returns (G, c, shifted cons_b, errors [B, 2], status [B])."""
+    ref = problem.J
+    B, n, m = int(ref.shape[0]), problem.n, problem.m
+    plan = _Plan(n, problem.k, m, problem.m_r, ref.dtype, ref.device, B)
+    G = torch.empty(B, n, n, dtype=ref.dtype, device=ref.device)
+    c = torch.empty(B, n, dtype=ref.dtype, device=ref.device)
+    cb = torch.empty(B, m, dtype=ref.dtype, device=ref.device)
+    err = torch.empty(B, 2, dtype=ref.dtype, device=ref.device)
+    status = torch.empty(B, dtype=torch.int32, device=ref.device)
+    prob = problem.as_struct()
+    L.check(L.lib().mo_fill_qp(plan.h, C.byref(prob), B, _ptr(x), n, _ptr(G), n * n, n, _ptr(c), n, _ptr(cb), m, _ptr(err),
+                               _ptr(status), _stream()))
+    return G, c, cb, err, status
+
+
+def qp_cost_derivative(problem: BatchedQP, dx: torch.Tensor):
+    """ComputeQPCostDerivative (nonlinear.cc:452-483): ([B, 2] = {d_f, d_equality}, dx^T G dx [B])."""
+    ref = problem._any()
+    B, n = int(ref.shape[0]), problem.n
+    plan = _Plan(n, problem.k, 0, problem.m_r, ref.dtype, ref.device, B)
+    out = torch.empty(B, 2, dtype=ref.dtype, device=ref.device)
+    quad = torch.empty(B, dtype=ref.dtype, device=ref.device)
+    q = BatchedQP(n=n, k=problem.k, J=problem.J, r=problem.r, lam=problem.lam, lam_vec=problem.lam_vec, G=problem.G, c=problem.c,
+                  A_eq=problem.A_eq, b_eq=problem.b_eq)
+    prob = q.as_struct()
+    L.check(L.lib().mo_qp_cost_derivative(plan.h, C.byref(prob), B, _ptr(dx), n, _ptr(out), _ptr(quad), _stream()))
+    return out, quad

@@ -19,14 +19,14 @@ import scipy.linalg
 
 from . import oracle as orc
 
-# NLSTerminationState, structs.hpp
-(MAX_ITERATIONS, SATISFIED_ABSOLUTE_TOL, SATISFIED_RELATIVE_TOL, SATISFIED_FIRST_ORDER_TOL, QP_INDEFINITE, MAX_LAMBDA,
- USER_CALLBACK) = range(7)
-# StepSizeSelectionResult, structs.hpp
+# NLSTerminationState
+(MAX_ITERATIONS, SATISFIED_ABSOLUTE_TOL, SATISFIED_RELATIVE_TOL, SATISFIED_FIRST_ORDER_TOL, MAX_LAMBDA, QP_INDEFINITE,
+ USER_CALLBACK) = range(7)                                 # structs.hpp:233-248
+# StepSizeSelectionResult, structs.hpp:215-228
 (STEP_SUCCESS, STEP_MAX_ITERATIONS, STEP_FIRST_ORDER_SATISFIED, STEP_POSITIVE_DERIVATIVE, STEP_FAILURE_NON_FINITE_COST,
  STEP_FAILURE_INVALID_ALPHA) = range(6)
 NOMINAL, ATTEMPTING_RESTORE_LM = 0, 1                      # OptimizerState
-POLYNOMIAL_APPROXIMATION, ARMIJO_BACKTRACK = 0, 1          # LineSearchStrategy
+ARMIJO_BACKTRACK, POLYNOMIAL_APPROXIMATION = 0, 1          # LineSearchStrategy, structs.hpp:148-153
 
 
 @dataclass

@@ -1,0 +1,176 @@
+"""GPU parity tests of the SQP outer loop: mo_fill_qp / mo_nonlinear_errors /
+mo_qp_cost_derivative against numpy, and mo_nls_solve against the NLS oracle on the reference's own test problems
+(nonlinear_test.cc:390-826), every initial guess of a test being one problem of the batch."""
+import numpy as np
+import pytest
+import torch
+
+from mini_opt_amd import nls as NLS
+from mini_opt_amd import qp as Q
+from oracle import nls_oracle as N
+from tests import nls_problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dt=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0").contiguous()
+
+
+def test_fill_qp_errors_and_derivative_vs_numpy():
+    rng = np.random.default_rng(5)
+    B, n, k, m, m_r = 37, 12, 3, 7, 20
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, k, n)); b = rng.uniform(-1, 1, (B, k)); b[:, 0] = 0.0    # sign(0) = 0 (nonlinear.cc:440-450)
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(-1, 1, (B, m))
+    x = rng.uniform(-2, 2, (B, n)); dx = rng.uniform(-1, 1, (B, n))
+    lam = rng.uniform(0, 0.5, B); lam[::3] = 0.0
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam_vec=T(lam), A_eq=T(A.transpose(0, 2, 1)), b_eq=T(b),
+                       cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    G, c, cbs, err, status = NLS.fill_qp(prob, T(x))
+    assert torch.all(status == 0)
+    Gref = np.einsum("bqi,bqj->bij", J, J) + lam[:, None, None] * np.eye(n)
+    Gl = np.tril(G.cpu().numpy().transpose(0, 2, 1))
+    np.testing.assert_allclose(Gl, np.tril(Gref), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cbs.cpu().numpy(), ca * np.take_along_axis(x, cv, 1) + cb, rtol=1e-14, atol=1e-14)   # ShiftTo
+    np.testing.assert_allclose(err.cpu().numpy(), np.stack([0.5 * np.sum(r * r, 1), np.sum(np.abs(b), 1)], 1), rtol=1e-13)
+    # directional derivatives, J-level and QP-level
+    dref = np.stack([np.einsum("bi,bi->b", np.einsum("bqi,bq->bi", J, r), dx),
+                     np.einsum("bk,bk->b", np.sign(b), np.einsum("bkn,bn->bk", A, dx))], 1)
+    qref = np.einsum("bi,bij,bj->b", dx, Gref, dx)
+    d1, q1 = NLS.qp_cost_derivative(prob, T(dx))
+    np.testing.assert_allclose(d1.cpu().numpy(), dref, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(q1.cpu().numpy(), qref, rtol=1e-11)
+    prob2 = Q.BatchedQP(n=n, k=k, G=G, c=c, A_eq=T(A.transpose(0, 2, 1)), b_eq=T(b))
+    d2, q2 = NLS.qp_cost_derivative(prob2, T(dx))
+    np.testing.assert_allclose(d2.cpu().numpy(), dref, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(q2.cpu().numpy(), qref, rtol=1e-11)
+    # a bad constraint index is reported per problem
+    cv2 = cv.copy(); cv2[4, 2] = n
+    prob.cons_var = T(cv2, torch.int32)
+    _, _, cbs2, _, st2 = NLS.fill_qp(prob, T(x))
+    st2 = st2.cpu().numpy()
+    assert st2[4] == 4 and np.all(np.delete(st2, 4) == 0) and np.isnan(cbs2.cpu().numpy()[4, 2])
+
+
+def run_both(oprob, dprob, oparams, dparams, guesses):
+    """Solve every guess with the oracle (one at a time) and on the device (one batch)."""
+    guesses = np.array(guesses, dtype=float)
+    B = len(guesses)
+    nls = NLS.ConstrainedNonlinearLeastSquares(dprob, batch=B)
+    out = nls.Solve(dparams, T(guesses))
+    dev_x = nls.variables().cpu().numpy()
+    dev_term = out.termination_state.cpu().numpy(); dev_nit = out.num_iterations.cpu().numpy()
+    ref = N.ConstrainedNonlinearLeastSquares(oprob)
+    ref_x, ref_term, ref_nit, ref_logs = [], [], [], []
+    for g in guesses:
+        term, logs = ref.solve(oparams, g)
+        ref_x.append(ref.variables.copy()); ref_term.append(term); ref_nit.append(len(logs)); ref_logs.append(logs)
+    return out, dev_x, dev_term, dev_nit, np.array(ref_x), np.array(ref_term), np.array(ref_nit), ref_logs
+
+
+def params_pair(**kw):
+    return N.Params(**kw), NLS.Params(**kw)
+
+
+def check_records(out, ref_logs, p, rtol=1e-6):
+    """Per-iteration NLSIteration records of problem p against the oracle's log."""
+    rec = out.iterations.cpu().numpy()[p]
+    for i, lg in enumerate(ref_logs[p]):
+        exp = [lg.state, lg.lam, lg.errors_pre.f, lg.errors_pre.equality, lg.d_f, lg.d_eq, lg.penalty, lg.step_result, len(lg.steps)]
+        np.testing.assert_allclose(rec[i][:9], exp, rtol=rtol, atol=1e-9, err_msg=f"problem {p} iteration {i}")
+        for j, (alpha, e) in enumerate(lg.steps):
+            np.testing.assert_allclose(rec[i][12 + 3 * j:15 + 3 * j], [alpha, e.f, e.equality], rtol=rtol, atol=1e-9)
+
+
+def test_rosenbrock_and_lm():
+    # nonlinear_test.cc:390-461
+    oprob = N.Problem(2, P.rosenbrock_np)
+    dprob = NLS.Problem(2, P.rosenbrock_torch, cost_rows=2)
+    for kw in (dict(max_iterations=5, max_qp_iterations=1),
+               dict(max_iterations=10, max_qp_iterations=1, absolute_first_derivative_tol=1e-12, max_line_search_iterations=0)):
+        op, dp = params_pair(**kw)
+        out, x, term, nit, rx, rterm, rnit, logs = run_both(oprob, dprob, op, dp, P.ROSENBROCK_GUESSES)
+        assert np.all(term == NLS.SATISFIED_ABSOLUTE_TOL)
+        np.testing.assert_allclose(x, np.ones_like(x), atol=1e-6)
+        assert np.array_equal(term, rterm) and np.array_equal(nit, rnit)
+        assert np.array_equal(out.NumQPIterations().cpu().numpy(), nit)       # ASSERT_EQ(NumQPIterations(), iterations.size())
+        for p in range(len(x)):
+            check_records(out, logs, p)
+
+
+def test_inequality_constrained_rosenbrock():
+    # nonlinear_test.cc:463-500
+    cons = [(0, 1.0, -1.2), (1, -1.0, 0.5)]
+    op, dp = params_pair(max_iterations=10, max_qp_iterations=10)
+    out, x, term, nit, rx, rterm, rnit, logs = run_both(N.Problem(2, P.rosenbrock_np, inequality_constraints=cons),
+                                                        NLS.Problem(2, P.rosenbrock_torch, cost_rows=2, inequality_constraints=cons),
+                                                        op, dp, P.ROSENBROCK_CONSTRAINED_GUESSES)
+    assert not np.any((term == NLS.MAX_ITERATIONS) | (term == NLS.MAX_LAMBDA))
+    np.testing.assert_allclose(x, np.tile([1.2, 0.5], (len(x), 1)), atol=1e-6)
+    assert np.array_equal(term, rterm) and np.array_equal(nit, rnit)
+    np.testing.assert_allclose(x, rx, atol=1e-7)
+
+
+def test_inequality_constrained_rosenbrock_6d():
+    # nonlinear_test.cc:524-576
+    op, dp = params_pair(max_iterations=30, max_qp_iterations=30, relative_exit_tol=1e-6, absolute_first_derivative_tol=5e-6,
+                         termination_kkt_tolerance=1e-6, max_lambda=10.0)
+    out, x, term, nit, rx, rterm, rnit, logs = run_both(
+        N.Problem(6, P.rosenbrock6_np, inequality_constraints=P.ROSENBROCK6_CONSTRAINTS),
+        NLS.Problem(6, P.rosenbrock6_torch, cost_rows=10, inequality_constraints=P.ROSENBROCK6_CONSTRAINTS), op, dp, P.ROSENBROCK6_GUESSES)
+    assert np.all(NLS.TerminationStateIndicatesSatisfiedTol(torch.as_tensor(term)).numpy())
+    np.testing.assert_allclose(x, np.tile(P.ROSENBROCK6_SOLUTION, (len(x), 1)), atol=1e-5)
+    np.testing.assert_allclose(x, rx, atol=1e-5)
+
+
+@pytest.mark.parametrize("quadrant", [False, True])
+def test_himmelblau_grids(quadrant):
+    # nonlinear_test.cc:597-720: 961 (resp. 576) starts as ONE batch
+    cons = P.box(0.1, 5.0) if quadrant else P.box(-5.0, 5.0)
+    guesses = P.himmelblau_quadrant_guesses() if quadrant else P.himmelblau_guesses()
+    op, dp = params_pair(max_iterations=20, max_qp_iterations=10, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-8,
+                         termination_kkt_tolerance=1e-6)
+    out, x, term, nit, rx, rterm, rnit, logs = run_both(N.Problem(2, P.himmelblau_np, inequality_constraints=cons),
+                                                        NLS.Problem(2, P.himmelblau_torch, cost_rows=2, inequality_constraints=cons),
+                                                        op, dp, guesses)
+    assert np.all(NLS.TerminationStateIndicatesSatisfiedTol(torch.as_tensor(term)).numpy())
+    sols = np.array([(3.0, 2.0)] if quadrant else P.HIMMELBLAU_SOLUTIONS)
+    dist = np.min(np.linalg.norm(x[:, None, :] - sols[None], axis=2), axis=1)
+    assert dist.max() < 5e-5
+    # problem-by-problem agreement with the oracle's run of the reference algorithm (knife-edge branch decisions may flip
+    # with rounding in a few starts; those still have to reach an optimum, checked above)
+    same = (term == rterm) & (nit == rnit)
+    assert same.mean() > 0.97, same.mean()
+    np.testing.assert_allclose(x[same], rx[same], atol=1e-6)
+
+
+def test_sphere_with_nonlinear_equality_constraints():
+    # nonlinear_test.cc:745-826 (m = 0, k = 2: the reference's null-space path)
+    op, dp = params_pair(max_iterations=100, max_qp_iterations=1, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-9,
+                         termination_kkt_tolerance=1e-6, lambda_initial=0.001)
+    out, x, term, nit, rx, rterm, rnit, logs = run_both(N.Problem(6, P.sphere_np, equality=P.sphere_eq_np),
+                                                        NLS.Problem(6, P.sphere_torch, cost_rows=6, equality=P.sphere_eq_torch, equality_rows=2),
+                                                        op, dp, P.sphere_guesses(100))
+    assert np.all(NLS.TerminationStateIndicatesSatisfiedTol(torch.as_tensor(term)).numpy())
+    sols = np.array(P.SPHERE_SOLUTIONS)
+    dist = np.min(np.linalg.norm(x[:, None, :] - sols[None], axis=2), axis=1)
+    assert dist.max() < 5e-5
+    assert int(out.NumFailedLineSearches().sum()) == 0
+    same = (term == rterm) & (nit == rnit)
+    assert same.mean() > 0.9, same.mean()
+    np.testing.assert_allclose(x[same], rx[same], atol=1e-6)
+
+
+def test_nls_argument_errors_and_callback_failure():
+    dprob = NLS.Problem(2, P.rosenbrock_torch, cost_rows=2)
+    nls = NLS.ConstrainedNonlinearLeastSquares(dprob, batch=3)
+    from mini_opt_amd import _lib as L
+    with pytest.raises(L.MiniOptError):
+        nls.Solve(NLS.Params(max_qp_iterations=0), T(np.zeros((3, 2))))           # CheckParams, nonlinear.cc:48-73
+    with pytest.raises(L.MiniOptError):
+        nls.Solve(NLS.Params(armijo_search_tau=1.0), T(np.zeros((3, 2))))
+    bad = NLS.Problem(2, lambda x, w: (_ for _ in ()).throw(ValueError("boom")), cost_rows=2)
+    with pytest.raises(ValueError):
+        NLS.ConstrainedNonlinearLeastSquares(bad, batch=3).Solve(NLS.Params(), T(np.zeros((3, 2))))
