@@ -20,6 +20,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <exception>
+#include <functional>
 #include <limits>
 #include <optional>
 #include <stdexcept>
@@ -312,6 +314,139 @@ class BatchedQPInteriorPointSolver {
   mo_plan* plan() const { return plan_; }
  private:
   mo_plan* plan_{nullptr};
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ConstrainedNonlinearLeastSquares (nonlinear.hpp:127-230) for a batch of problems of one structure.  The reference's
+// residuals are host functors (residual.hpp:28-143); this facade keeps them on the host -- `HostResiduals` is called with the
+// evaluation points of ALL problems and fills dense stacks -- and ships the stacks to the device, where the whole SQP
+// iteration (QP, penalty, line search, lambda state machine) runs behind mo_nls_solve.  Callers with device-side residual
+// kernels bind mo_nls_solve directly and skip the PCIe hops.
+enum class NLSTerminationState { MAX_ITERATIONS = 0, SATISFIED_ABSOLUTE_TOL, SATISFIED_RELATIVE_TOL, SATISFIED_FIRST_ORDER_TOL,
+                                 MAX_LAMBDA, QP_INDEFINITE, USER_CALLBACK, QP_FAILURE };                  // structs.hpp:233-248
+enum class LineSearchStrategy { ARMIJO_BACKTRACK = 0, POLYNOMIAL_APPROXIMATION = 1 };                    // structs.hpp:148-153
+
+class BatchedConstrainedNonlinearLeastSquares {
+ public:
+  struct Params {                                                                                        // nonlinear.hpp:64-124
+    int max_iterations{10};
+    int max_qp_iterations{10};
+    double termination_kkt_tolerance{1.0e-6};
+    double absolute_exit_tol{1.0e-12};
+    double relative_exit_tol{1.0e-5};
+    double absolute_first_derivative_tol{1.0e-6};
+    int max_line_search_iterations{2};
+    LineSearchStrategy line_search_strategy{LineSearchStrategy::POLYNOMIAL_APPROXIMATION};
+    double armijo_search_tau{0.8};
+    double equality_penalty_initial{1.0};
+    double equality_penalty_scale_factor{1.01};
+    double equality_penalty_rho{0.1};
+    double lambda_initial{0.0};
+    double lambda_failure_init{1.0e-2};
+    double lambda_decrease_on_success{0.1};
+    double lambda_decrease_on_restore{0.8};
+    double max_lambda{1.};
+    double min_lambda{0.};
+  };
+  // x: [batch][n] evaluation points.  r: [batch][m_r], J: [batch][m_r][n] row-major (NULL when only errors are wanted),
+  // r_eq: [batch][k], J_eq: [batch][k][n] row-major (both NULL when k == 0).
+  using HostResiduals = std::function<void(const double* x, int64_t batch, double* r, double* J, double* r_eq, double* J_eq)>;
+
+  BatchedConstrainedNonlinearLeastSquares(int n, int m_r, int k, std::vector<LinearInequalityConstraint> inequality_constraints,
+                                          HostResiduals residuals, int64_t batch, int device = 0)
+      : n_(n), m_r_(m_r), k_(k), m_((int)inequality_constraints.size()), batch_(batch), residuals_(std::move(residuals)) {
+    mo_plan_desc d{}; d.n = n; d.k = k; d.m = m_; d.m_r = m_r; d.dtype = MO_F64; d.device = device; d.max_batch = batch;
+    detail::check(mo_plan_create(&d, &plan_));
+    std::vector<int32_t> cv; std::vector<double> ca, cb;
+    for (const auto& c : inequality_constraints) {
+      if (c.variable < 0 || c.variable >= n) throw default_error("constraint index out of range");   // F_ASSERT_LT qp.hpp:63
+      cv.push_back(c.variable); ca.push_back(c.a); cb.push_back(c.b);
+    }
+    cv_.Upload(cv.data(), cv.size()); ca_.Upload(ca.data(), ca.size()); cb_.Upload(cb.data(), cb.size());
+    const size_t B = (size_t)batch;
+    vars_.Resize(B * n); cand_.Resize(B * n); J_.Resize(B * m_r * n); r_.Resize(B * m_r); r_cand_.Resize(B * m_r);
+    Jeq_.Resize(B * k * n); req_.Resize(B * k); req_cand_.Resize(B * k);
+    h_x_.resize(B * n); h_J_.resize(B * m_r * n); h_r_.resize(B * m_r); h_Jeq_.resize(B * k * n); h_JeqT_.resize(B * k * n); h_req_.resize(B * k);
+  }
+  ~BatchedConstrainedNonlinearLeastSquares() { if (plan_) mo_plan_destroy(plan_); }
+  BatchedConstrainedNonlinearLeastSquares(const BatchedConstrainedNonlinearLeastSquares&) = delete;
+  BatchedConstrainedNonlinearLeastSquares& operator=(const BatchedConstrainedNonlinearLeastSquares&) = delete;
+
+  // Solve(params, variables), nonlinear.cc:75-158: variables is [batch][n]; returns the termination state of every problem.
+  std::vector<NLSTerminationState> Solve(const Params& p, const std::vector<double>& variables) {
+    if ((int64_t)variables.size() != batch_ * n_) throw default_error("variables must be batch x n");
+    vars_.Upload(variables.data(), variables.size());
+    mo_nls_params sp; mo_default_nls_params(&sp);
+    sp.max_iterations = p.max_iterations; sp.max_qp_iterations = p.max_qp_iterations;
+    sp.termination_kkt_tolerance = p.termination_kkt_tolerance; sp.absolute_exit_tol = p.absolute_exit_tol;
+    sp.relative_exit_tol = p.relative_exit_tol; sp.absolute_first_derivative_tol = p.absolute_first_derivative_tol;
+    sp.max_line_search_iterations = p.max_line_search_iterations; sp.line_search_strategy = (int32_t)p.line_search_strategy;
+    sp.armijo_search_tau = p.armijo_search_tau; sp.equality_penalty_initial = p.equality_penalty_initial;
+    sp.equality_penalty_scale_factor = p.equality_penalty_scale_factor; sp.equality_penalty_rho = p.equality_penalty_rho;
+    sp.lambda_initial = p.lambda_initial; sp.lambda_failure_init = p.lambda_failure_init;
+    sp.lambda_decrease_on_success = p.lambda_decrease_on_success; sp.lambda_decrease_on_restore = p.lambda_decrease_on_restore;
+    sp.max_lambda = p.max_lambda; sp.min_lambda = p.min_lambda;
+    mo_nls_problem np{};
+    np.vars = vars_.get(); np.vars_stride = n_; np.candidate = cand_.get(); np.candidate_stride = n_;
+    np.J = J_.get(); np.J_stride = (int64_t)m_r_ * n_; np.J_ld = n_; np.J_layout = MO_ROW_MAJOR; np.r = r_.get(); np.r_stride = m_r_;
+    np.r_cand = r_cand_.get(); np.r_cand_stride = m_r_;
+    if (k_ > 0) {
+      np.J_eq = Jeq_.get(); np.J_eq_stride = (int64_t)k_ * n_; np.J_eq_ld = k_; np.r_eq = req_.get(); np.r_eq_stride = k_;
+      np.r_eq_cand = req_cand_.get(); np.r_eq_cand_stride = k_;
+    }
+    if (m_ > 0) { np.cons_var = cv_.get(); np.cons_a = ca_.get(); np.cons_b = cb_.get(); np.cons_stride = 0; }
+    detail::DeviceBuffer<int32_t> term((size_t)batch_), nit((size_t)batch_);
+    callback_error_ = nullptr;
+    const int rc = mo_nls_solve(plan_, &np, batch_, &sp, &BatchedConstrainedNonlinearLeastSquares::Eval, this, term.get(), nit.get(),
+                                nullptr, nullptr, nullptr);
+    if (callback_error_) std::rethrow_exception(callback_error_);
+    detail::check(rc);
+    variables_.resize((size_t)batch_ * n_); vars_.Download(variables_.data(), variables_.size());
+    num_iterations_.resize((size_t)batch_); nit.Download(num_iterations_.data(), num_iterations_.size());
+    std::vector<int32_t> t((size_t)batch_); term.Download(t.data(), t.size());
+    std::vector<NLSTerminationState> out;
+    for (int32_t v : t) out.push_back((NLSTerminationState)v);
+    return out;
+  }
+  const std::vector<double>& variables() const { return variables_; }          // [batch][n]
+  const std::vector<int32_t>& num_iterations() const { return num_iterations_; }
+
+ private:
+  static int Eval(void* user, int32_t what, void* stream) {
+    auto* self = static_cast<BatchedConstrainedNonlinearLeastSquares*>(user);
+    try {
+      const bool lin = what == MO_NLS_EVAL_LINEARIZE;
+      const size_t B = (size_t)self->batch_, n = (size_t)self->n_, k = (size_t)self->k_;
+      (void)hipStreamSynchronize((hipStream_t)stream);  // the evaluation point is produced by device work on this stream
+      (lin ? self->vars_ : self->cand_).Download(self->h_x_.data(), B * n);
+      self->residuals_(self->h_x_.data(), self->batch_, self->h_r_.data(), lin ? self->h_J_.data() : nullptr,
+                       k ? self->h_req_.data() : nullptr, (lin && k) ? self->h_Jeq_.data() : nullptr);
+      (lin ? self->r_ : self->r_cand_).Upload(self->h_r_.data(), self->h_r_.size());
+      if (k) (lin ? self->req_ : self->req_cand_).Upload(self->h_req_.data(), self->h_req_.size());
+      if (lin) {
+        self->J_.Upload(self->h_J_.data(), self->h_J_.size());
+        if (k) {  // QP::A_eq is k x n column-major (Eigen default): transpose the row-major stack
+          for (size_t p = 0; p < B; ++p)
+            for (size_t i = 0; i < k; ++i)
+              for (size_t j = 0; j < n; ++j) self->h_JeqT_[p * k * n + j * k + i] = self->h_Jeq_[p * k * n + i * n + j];
+          self->Jeq_.Upload(self->h_JeqT_.data(), self->h_JeqT_.size());
+        }
+      }
+      return 0;
+    } catch (...) {
+      self->callback_error_ = std::current_exception();
+      return 1;
+    }
+  }
+  int n_, m_r_, k_, m_;
+  int64_t batch_;
+  HostResiduals residuals_;
+  mo_plan* plan_{nullptr};
+  detail::DeviceBuffer<double> vars_, cand_, J_, r_, r_cand_, Jeq_, req_, req_cand_, ca_, cb_;
+  detail::DeviceBuffer<int32_t> cv_;
+  std::vector<double> h_x_, h_J_, h_r_, h_Jeq_, h_JeqT_, h_req_, variables_;
+  std::vector<int32_t> num_iterations_;
+  std::exception_ptr callback_error_{nullptr};
 };
 
 }  // namespace mini_opt_hip

@@ -132,12 +132,84 @@ static void TestErrors() {
   EXPECT_TRUE(threw);  // CheckParams, qp.cc:76-82
 }
 
+// TestRosenbrock / TestInequalityConstrainedRosenbrock (nonlinear_test.cc:390-500) through the batched NLS facade: every
+// initial guess of the reference test is one problem of the batch; residuals are host functors as in the reference.
+static void RosenbrockHost(const double* x, int64_t batch, double* r, double* J, double*, double*) {
+  const double sb = std::sqrt(100.0);
+  for (int64_t p = 0; p < batch; ++p) {
+    const double x0 = x[2 * p], x1 = x[2 * p + 1];
+    r[2 * p] = 1.0 - x0; r[2 * p + 1] = sb * (x1 - x0 * x0);
+    if (J) { J[4 * p] = -1.0; J[4 * p + 1] = 0.0; J[4 * p + 2] = -2.0 * x0 * sb; J[4 * p + 3] = sb; }
+  }
+}
+static void TestNlsRosenbrock() {
+  const std::vector<double> guesses = {-5, -3, 10, 8, -20, 3, 0, -5, 4, 0, 100, 50, -35, 40, 1000, -50, 0.8, -0.3};
+  const int64_t B = (int64_t)guesses.size() / 2;
+  BatchedConstrainedNonlinearLeastSquares nls(2, 2, 0, {}, RosenbrockHost, B);
+  BatchedConstrainedNonlinearLeastSquares::Params p{};
+  p.max_iterations = 5; p.max_qp_iterations = 1;
+  const auto term = nls.Solve(p, guesses);
+  for (int64_t i = 0; i < B; ++i) {
+    EXPECT_TRUE(term[i] == NLSTerminationState::SATISFIED_ABSOLUTE_TOL);
+    EXPECT_NEAR(1.0, nls.variables()[2 * i], 1e-6);
+    EXPECT_NEAR(1.0, nls.variables()[2 * i + 1], 1e-6);
+  }
+  // Var(0) >= 1.2, Var(1) <= 0.5: the optimum sits on both constraints
+  const std::vector<double> g2 = {12, -5, 100.0, -20.0, 1423.0, -400.0, -20.0, 10.0, -120.0, 35.0, -50.0, 0.5};
+  BatchedConstrainedNonlinearLeastSquares nls2(2, 2, 0, {Var(0) >= 1.2, Var(1) <= 0.5}, RosenbrockHost, 6);
+  BatchedConstrainedNonlinearLeastSquares::Params p2{};
+  p2.max_iterations = 10; p2.max_qp_iterations = 10;
+  const auto term2 = nls2.Solve(p2, g2);
+  for (int i = 0; i < 6; ++i) {
+    EXPECT_TRUE(term2[i] != NLSTerminationState::MAX_ITERATIONS && term2[i] != NLSTerminationState::MAX_LAMBDA);
+    EXPECT_NEAR(1.2, nls2.variables()[2 * i], 1e-6);
+    EXPECT_NEAR(0.5, nls2.variables()[2 * i + 1], 1e-6);
+  }
+  // CheckParams (nonlinear.cc:48-73) surfaces as default_error
+  bool threw = false;
+  try { p2.armijo_search_tau = 1.5; (void)nls2.Solve(p2, g2); } catch (const default_error&) { threw = true; }
+  EXPECT_TRUE(threw);
+}
+
+// TestSphereWithNonlinearEqualityConstraints (nonlinear_test.cc:745-826): cost x (6 variables), x0 x1 = 4, x2 x3 = 9
+static void SphereHost(const double* x, int64_t batch, double* r, double* J, double* r_eq, double* J_eq) {
+  for (int64_t p = 0; p < batch; ++p) {
+    const double* xp = x + 6 * p;
+    for (int i = 0; i < 6; ++i) r[6 * p + i] = xp[i];
+    if (J) for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) J[36 * p + 6 * i + j] = i == j ? 1.0 : 0.0;
+    r_eq[2 * p] = xp[0] * xp[1] - 4.0; r_eq[2 * p + 1] = xp[2] * xp[3] - 9.0;
+    if (J_eq) {
+      double* Je = J_eq + 12 * p;
+      for (int i = 0; i < 12; ++i) Je[i] = 0.0;
+      Je[0] = xp[1]; Je[1] = xp[0]; Je[6 + 2] = xp[3]; Je[6 + 3] = xp[2];
+    }
+  }
+}
+static void TestNlsSphereWithEqualities() {
+  const std::vector<double> guesses = {5.0, 3.0, -7.0, -2.0, 4.0, -9.0,   -12.0, -1.5, 20.0, 6.0, -3.0, 8.0,   25.0, 14.0, 3.0, 22.0, -17.0, 1.0};
+  BatchedConstrainedNonlinearLeastSquares nls(6, 6, 2, {}, SphereHost, 3);
+  BatchedConstrainedNonlinearLeastSquares::Params p{};
+  p.max_iterations = 100; p.max_qp_iterations = 1; p.relative_exit_tol = 1e-12; p.absolute_first_derivative_tol = 1e-9;
+  p.termination_kkt_tolerance = 1e-6; p.lambda_initial = 0.001;
+  const auto term = nls.Solve(p, guesses);
+  for (int i = 0; i < 3; ++i) {
+    EXPECT_TRUE(term[i] == NLSTerminationState::SATISFIED_ABSOLUTE_TOL || term[i] == NLSTerminationState::SATISFIED_RELATIVE_TOL ||
+                term[i] == NLSTerminationState::SATISFIED_FIRST_ORDER_TOL);
+    const double* v = nls.variables().data() + 6 * i;
+    EXPECT_NEAR(2.0, std::fabs(v[0]), 5e-5); EXPECT_NEAR(v[0], v[1], 5e-5);
+    EXPECT_NEAR(3.0, std::fabs(v[2]), 5e-5); EXPECT_NEAR(v[2], v[3], 5e-5);
+    EXPECT_NEAR(0.0, v[4], 5e-5); EXPECT_NEAR(0.0, v[5], 5e-5);
+  }
+}
+
 int main() {
   TestLinearInequalityConstraint();
   TestEliminationAllConstraints();
   TestWithInequalitiesAndEqualities();
   TestWithFullyConstrainedEqualities();
   TestErrors();
+  TestNlsRosenbrock();
+  TestNlsSphereWithEqualities();
   if (g_fail) { std::printf("%d FAILURES\n", g_fail); return 1; }
   std::printf("facade_test: all tests passed\n");
   return 0;

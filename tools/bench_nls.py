@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Secondary measurement: the batched SQP loop (mo_nls_solve) on a many-start Himmelblau sweep (nonlinear_test.cc:597-664
+scaled up), with the oracle's single-problem loop timed beside it on a sample.  usage: python tools/bench_nls.py [starts]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+from mini_opt_amd import nls as NLS
+from tests import nls_problems as P
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    rng = np.random.default_rng(0)
+    guesses = rng.uniform(-4.5, 4.5, (B, 2))
+    cons = P.box(-5.0, 5.0)
+    kw = dict(max_iterations=20, max_qp_iterations=10, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-8,
+              termination_kkt_tolerance=1e-6)
+    nls = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, P.himmelblau_torch, cost_rows=2, inequality_constraints=cons), batch=B)
+    g = torch.as_tensor(guesses, device="cuda:0")
+    nls.Solve(NLS.Params(**kw), g); torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = nls.Solve(NLS.Params(**kw), g); torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    x = nls.variables().cpu().numpy()
+    sols = np.array(P.HIMMELBLAU_SOLUTIONS)
+    dist = np.min(np.linalg.norm(x[:, None, :] - sols[None], axis=2), axis=1)
+    res = {"problem": "Himmelblau, box [-5, 5]^2", "starts": B, "seconds": dt, "problems_per_s": B / dt,
+           "satisfied_frac": float(NLS.TerminationStateIndicatesSatisfiedTol(out.termination_state).double().mean()),
+           "at_an_optimum_frac": float((dist < 5e-5).mean()), "mean_outer_iterations": float(out.num_iterations.double().mean()),
+           "mean_qp_iterations": float(out.NumQPIterations().double().mean())}
+    try:
+        from oracle import nls_oracle as N
+        ref = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.himmelblau_np, inequality_constraints=cons))
+        ns = min(B, 256)
+        t = time.perf_counter()
+        for gi in guesses[:ns]:
+            ref.solve(N.Params(**kw), gi)
+        res["oracle_problems_per_s_1core"] = ns / (time.perf_counter() - t)
+    except Exception as e:  # the oracle is optional here
+        res["oracle_error"] = str(e)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
