@@ -53,6 +53,7 @@ extern "C" {
 #define MO_STATUS_FACTORIZATION_FAILED 2 /* FailedFactorization (qp.cc:303-307, qp.hpp:331-333) */
 #define MO_STATUS_NONFINITE 3            /* the computed direction contains NaN/Inf */
 #define MO_STATUS_BAD_INDEX 4            /* constraint variable index outside [0,n) (F_ASSERT qp.cc:70-72) */
+#define MO_STATUS_NOT_POSITIVE_DEFINITE 5 /* mo_nullspace_solve: QPNullSpaceTerminationState::NOT_POSITIVE_DEFINITE (qp.cc:711-713) */
 
 typedef enum { MO_F64 = 0, MO_F32 = 1 } mo_dtype;
 typedef enum { MO_COL_MAJOR = 0, MO_ROW_MAJOR = 1 } mo_layout;
@@ -205,6 +206,17 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
                 int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
                 int32_t* status, void* stream);
 
+/* Replaces QPNullSpaceSolver::Solve (qp.cc:679-729): minimise 1/2 x^T G x + c^T x subject to A_eq x + b_eq = 0 (k >= 1, no
+ * inequalities; the plan's m is ignored).  x_out [batch][n] = QPNullSpaceSolver::variables(); termination [batch] =
+ * QPNullSpaceTerminationState (structs.hpp:137-142): 0 SUCCESS, 1 NOT_POSITIVE_DEFINITE (x_out is NaN then).
+ * The reference projects G into null(A_eq) with a pivoted Householder QR and Cholesky-factors the reduced Hessian; here the
+ * same minimiser comes from the LDL^T of the KKT matrix, and "reduced Hessian positive definite" is read off its inertia
+ * (exactly k negative pivots) -- same answers, no QR.  Rank-deficient A_eq (which the reference's rank-revealing QR
+ * tolerates) is reported as NOT_POSITIVE_DEFINITE. */
+typedef enum { MO_NULLSPACE_SUCCESS = 0, MO_NULLSPACE_NOT_POSITIVE_DEFINITE = 1 } mo_nullspace_termination;
+int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, void* x_out, int64_t x_stride,
+                       int32_t* termination, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Batched constrained nonlinear least squares: ConstrainedNonlinearLeastSquares::Solve (nonlinear.cc:75-158) for a batch of
  * independent problems of one shape, every problem with its own lambda / penalty / optimizer state, in lock step.
@@ -218,7 +230,8 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
  * fp64 plans only.  A problem whose QP fails (status != MO_STATUS_OK; the reference throws there) ends with
  * MO_NLS_QP_FAILURE and its QP status in status[p].  With equality constraints and no inequalities the reference switches
  * to QPNullSpaceSolver (nonlinear.cc:83-86); here the same step comes from the KKT factorisation and the penalty follows
- * the no-multiplier branch of SelectPenalty (nonlinear.cc:491-499) as the reference's does; QP_INDEFINITE is not detected. */
+ * the no-multiplier branch of SelectPenalty (nonlinear.cc:491-499) as the reference's does; a KKT matrix that cannot be
+ * factorised there ends the problem with MO_NLS_QP_INDEFINITE (G = J^T J + lambda I is never indefinite, only singular). */
 typedef enum { MO_NLS_MAX_ITERATIONS = 0, MO_NLS_SATISFIED_ABSOLUTE_TOL = 1, MO_NLS_SATISFIED_RELATIVE_TOL = 2,
                MO_NLS_SATISFIED_FIRST_ORDER_TOL = 3, MO_NLS_MAX_LAMBDA = 4, MO_NLS_QP_INDEFINITE = 5,
                MO_NLS_USER_CALLBACK = 6, MO_NLS_QP_FAILURE = 7 } mo_nls_termination;   /* NLSTerminationState, structs.hpp:233-248 */

@@ -17,14 +17,15 @@ MO_F64, MO_F32 = 0, 1
 MO_COL_MAJOR, MO_ROW_MAJOR = 0, 1
 MO_PLAN_FORCE_GENERIC = 1
 MO_STEP_NO_INEQUALITIES = 1
-MO_STATUS_OK, MO_STATUS_NONPOSITIVE_SLACK, MO_STATUS_FACTORIZATION_FAILED, MO_STATUS_NONFINITE, MO_STATUS_BAD_INDEX = range(5)
+(MO_STATUS_OK, MO_STATUS_NONPOSITIVE_SLACK, MO_STATUS_FACTORIZATION_FAILED, MO_STATUS_NONFINITE, MO_STATUS_BAD_INDEX,
+ MO_STATUS_NOT_POSITIVE_DEFINITE) = range(6)
 MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
 
 # every symbol include/mini_opt_hip.h declares
 EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
            "mo_plan_destroy", "mo_plan_step_kernel", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
            "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative",
-           "mo_default_nls_params", "mo_nls_solve"]
+           "mo_default_nls_params", "mo_nls_solve", "mo_nullspace_solve"]
 
 
 class PlanDesc(C.Structure):
@@ -120,6 +121,7 @@ def lib() -> C.CDLL:
     L.mo_fill_qp.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp, vp, vp]
     L.mo_nonlinear_errors.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp]
     L.mo_qp_cost_derivative.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp, vp]
+    L.mo_nullspace_solve.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp]
     L.mo_default_nls_params.argtypes = [C.POINTER(NlsParams)]
     L.mo_default_nls_params.restype = None
     L.mo_nls_solve.argtypes = [vp, C.POINTER(NlsProblem), i64, C.POINTER(NlsParams), NLS_EVAL_FN, vp, vp, vp, vp, vp, vp]

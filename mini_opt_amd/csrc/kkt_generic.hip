@@ -508,6 +508,8 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
     if (a.vars && MODE != MODE_LINEARIZE) {
       const T* vp = (const T*)a.vars + p * a.vars_stride;
       for (int i = tid; i < V; i += kThreads) w.vars[i] = vp[i];
+    } else if (MODE == MODE_STEP) {  // mo_nullspace_solve: the step from x = y = 0 IS the minimiser
+      for (int i = tid; i < V; i += kThreads) w.vars[i] = (T)0;
     }
     T mu_p = (T)0;
     if (a.mu) mu_p = ((const T*)a.mu)[p * a.mu_stride];
@@ -557,6 +559,18 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
         MO_GSTAMP(3);
         if (no_ineq) {
           st = assemble_and_factor(w, n, k, m, false, tid);
+          if (st == MO_STATUS_OK && (a.flags & MO_STEP_NULLSPACE)) {
+            // QPNullSpaceSolver's LLT of the reduced Hessian Z^T G Z succeeds iff it is positive definite (qp.cc:709-713), i.e.
+            // (A_eq of full row rank) iff the KKT matrix has inertia (n, k, 0): count the negative pivots of D (Sylvester).
+            int neg = 0;
+            for (int i = tid; i < n + k; i += kThreads) neg += (w.invd[i] < (T)0) ? 1 : 0;
+            neg = wave_sum(neg);
+            if ((tid & 63) == 0) atomicAdd(&w.iflag[4], neg);
+            __syncthreads();
+            if (w.iflag[4] != k) st = MO_STATUS_NOT_POSITIVE_DEFINITE;
+          } else if (a.flags & MO_STEP_NULLSPACE) {
+            st = MO_STATUS_NOT_POSITIVE_DEFINITE;  // a zero pivot: the reduced Hessian (or A_eq A_eq^T) is singular
+          }
           if (st == MO_STATUS_OK) solve_for_update(w, n, k, m, (T)0, false, tid);
           ip[0] = mu_p; ip[1] = 1; ip[2] = 1; ip[3] = ip[4] = ip[5] = nanT<T>();
         } else {
@@ -579,7 +593,8 @@ __global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs 
       }
       if (a.delta) {
         T* dp = (T*)a.delta + p * a.delta_stride;
-        for (int i = tid; i < V; i += kThreads) dp[i] = st == MO_STATUS_OK ? w.delta[i] : nanT<T>();
+        const int nout = (a.flags & MO_STEP_NULLSPACE) ? n : V;  // mo_nullspace_solve returns x only (QPNullSpaceSolver::variables())
+        for (int i = tid; i < nout; i += kThreads) dp[i] = st == MO_STATUS_OK ? w.delta[i] : nanT<T>();
       }
       if (tid == 0) {  // constant indices only: a runtime-indexed register array would live in scratch
         if (a.alpha) {

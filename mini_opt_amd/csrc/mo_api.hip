@@ -132,6 +132,7 @@ const char* mo_status_string(int32_t status) {
     case MO_STATUS_FACTORIZATION_FAILED: return "FACTORIZATION_FAILED";
     case MO_STATUS_NONFINITE: return "NONFINITE";
     case MO_STATUS_BAD_INDEX: return "BAD_INDEX";
+    case MO_STATUS_NOT_POSITIVE_DEFINITE: return "NOT_POSITIVE_DEFINITE";
     default: return "UNKNOWN";
   }
 }
@@ -399,6 +400,31 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
   }
   return launch(plan, a, stream);  // fused Solve kernel for J-level n = 32 / 64 fp64 problems, generic kernel otherwise
+}
+
+int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, void* x_out, int64_t x_stride,
+                       int32_t* termination, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  if (plan->desc.k <= 0) return fail(MO_ERR_DIMENSION, "Problem must have at least one equality constraint");  // F_ASSERT_GT qp.cc:680
+  if (!x_out || !termination) return fail(MO_ERR_INVALID_ARGUMENT, "x_out / termination is NULL");
+  mo_plan tmp = *plan;
+  tmp.desc.m = 0;  // no inequalities on this path
+  tmp.desc.flags |= MO_PLAN_FORCE_GENERIC;
+  mo::KernelArgs a;
+  if (int rc = fill_problem(&tmp, prob, batch, true, false, &a)) return rc;
+  a.mode = mo::MODE_STEP;
+  a.flags = MO_STEP_NO_INEQUALITIES | MO_STEP_NULLSPACE;
+  a.tau = 1.0;
+  a.delta = x_out; a.delta_stride = x_stride;
+  a.status = termination;  // MO_STATUS_OK -> 0 SUCCESS; translated below
+  if (int rc = launch(&tmp, a, stream)) return rc;
+  // status word -> QPNullSpaceTerminationState: everything that is not OK means the reduced Hessian could not be factorised
+  mo::AuxArgs t;
+  memset(&t, 0, sizeof(t));
+  t.batch = batch; t.status = termination;
+  MO_HIP_CHECK(mo::launch_nullspace_termination(t, (hipStream_t)stream));
+  return MO_OK;
 }
 
 void mo_default_nls_params(mo_nls_params* p) {

@@ -7,6 +7,9 @@
 
 namespace mo {
 
+// internal step flag (beside the public MO_STEP_*): mo_nullspace_solve -- state = 0, inertia check, x block only
+#define MO_STEP_NULLSPACE 0x100u
+
 enum Mode : int {
   MODE_LINEARIZE = 0,  // nonlinear.cc:182-189 (J^T J, J^T r)
   MODE_RESIDUAL = 1,   // qp.cc:391-437
@@ -87,6 +90,7 @@ struct AuxArgs {
 hipError_t launch_shift_constraints(const AuxArgs& a, int dtype, hipStream_t stream);
 hipError_t launch_nonlinear_errors(const AuxArgs& a, int dtype, hipStream_t stream);
 hipError_t launch_cost_derivative(const AuxArgs& a, int dtype, hipStream_t stream);
+hipError_t launch_nullspace_termination(const AuxArgs& a, hipStream_t stream);  // status[p] = status[p] != 0
 
 // per-problem state machine of the batched SQP loop (mo_nls_solve), nls_kernels.hip; fp64 only
 enum { NLS_SD_LAMBDA = 0, NLS_SD_PENALTY, NLS_SD_ALPHA, NLS_SD_DIRECTIONAL, NLS_SD_A2, NLS_SD_T2, NLS_SD_A1, NLS_SD_T1, NLS_SD = 8 };

@@ -166,8 +166,11 @@ __global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) 
       rec[8] = 0; rec[9] = a.qp_term[p]; rec[10] = a.qp_nit[p]; rec[11] = qp_status;
     }
     if (qp_status != MO_STATUS_OK) {                       // the reference throws here (qp.cc:285, 303-307)
-      si[NLS_SI_TERM] = MO_NLS_QP_FAILURE;
-      si[NLS_SI_NITER] = a.iter + 1;
+      // with equalities and no inequalities the reference's null-space solver reports a reduced Hessian it cannot factorise and
+      // Solve returns QP_INDEFINITE without logging the iteration (nonlinear.cc:103-105)
+      const bool nullspace_path = a.m == 0 && a.k > 0;
+      si[NLS_SI_TERM] = nullspace_path ? MO_NLS_QP_INDEFINITE : MO_NLS_QP_FAILURE;
+      si[NLS_SI_NITER] = nullspace_path ? a.iter : a.iter + 1;
       if (a.status) a.status[p] = qp_status;
       if (rec) rec[0] = si[NLS_SI_STATE];
     } else {
@@ -287,6 +290,11 @@ __global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void nullspace_termination_kernel(const AuxArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p < a.batch) a.status[p] = a.status[p] != MO_STATUS_OK ? MO_NULLSPACE_NOT_POSITIVE_DEFINITE : MO_NULLSPACE_SUCCESS;
+}
+
 template <typename K64, typename K32>
 hipError_t launch_aux(K64 k64, K32 k32, const AuxArgs& a, int dtype, hipStream_t stream) {
   if (a.batch <= 0) return hipSuccess;
@@ -308,6 +316,11 @@ hipError_t launch_cost_derivative(const AuxArgs& a, int dtype, hipStream_t strea
   return launch_aux(cost_derivative_kernel<double>, cost_derivative_kernel<float>, a, dtype, stream);
 }
 
+hipError_t launch_nullspace_termination(const AuxArgs& a, hipStream_t stream) {
+  if (a.batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(nullspace_termination_kernel, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
 hipError_t launch_nls_init(const NlsArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(nls_init_kernel, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();

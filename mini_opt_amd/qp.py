@@ -294,6 +294,35 @@ class QPInteriorPointSolver:
         return SolverOutputs(term, nit, its, lag, self.status_)
 
 
+class QPNullSpaceSolver:
+    """Batched mirror of mini_opt::QPNullSpaceSolver (qp.hpp:296-315, qp.cc:679-729): equality-constrained QPs, no inequalities.
+    Solve returns QPNullSpaceTerminationState per problem (0 SUCCESS, 1 NOT_POSITIVE_DEFINITE); variables() is x [B, n]."""
+    SUCCESS, NOT_POSITIVE_DEFINITE = 0, 1
+
+    def __init__(self):
+        self.x_ = None
+
+    def Solve(self, p: BatchedQP) -> torch.Tensor:
+        lib = L.lib()
+        ref = p._any()
+        B = max(int(t.shape[0]) for t in (p.J, p.G, p.A_eq) if t is not None)
+        desc = L.PlanDesc(p.n, p.k, 0, p.m_r, _DT[p.dtype], ref.device.index or 0, 0, 0, B)
+        plan = C.c_void_p()
+        L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
+        try:
+            q = BatchedQP(n=p.n, k=p.k, J=p.J, r=p.r, lam=p.lam, lam_vec=p.lam_vec, G=p.G, c=p.c, A_eq=p.A_eq, b_eq=p.b_eq)
+            prob = q.as_struct()
+            self.x_ = torch.empty(B, p.n, dtype=ref.dtype, device=ref.device)
+            term = torch.empty(B, dtype=torch.int32, device=ref.device)
+            L.check(lib.mo_nullspace_solve(plan, C.byref(prob), B, _ptr(self.x_), p.n, _ptr(term), _stream()))
+        finally:
+            lib.mo_plan_destroy(plan)
+        return term
+
+    def variables(self) -> torch.Tensor:
+        return self.x_
+
+
 def linearize(problem: BatchedQP):
     """Cost part of LinearizeAndFillQP (nonlinear.cc:182-189): returns (G [B,n,n] col-major lower, c [B,n], 0.5|r|^2 [B])."""
     lib = L.lib()

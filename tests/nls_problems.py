@@ -158,3 +158,22 @@ def sphere_guesses(count=100, seed=7):
     """The reference draws U(-30, 30) from std::default_random_engine{7} (not portable); any guesses serve the test's purpose."""
     rng = np.random.default_rng(seed)
     return [tuple(rng.uniform(-30.0, 30.0, 6)) for _ in range(count)]
+
+
+def nullspace_kats():
+    """TestNullSpaceSolver1 / 2 (qp_test.cc:576-707): G = sum J^T J, c = sum J^T r at x = 0, one equality block, and the
+    values the reference asserts (index, value, tolerance)."""
+    A = np.array([[-2.0, 1.4], [2.2, -3.5]]); b = np.array([-0.8, 1.3])
+    k1 = dict(name="nullspace1", G=A.T @ A, c=A.T @ (-b), A_eq=np.array([[0.0, 1.0]]), b_eq=np.array([-0.3]),
+              expected=[(1, 0.3, 1e-12), (0, 0.860859728506787, 1e-12)])
+    G = np.zeros((4, 4)); c = np.zeros(4)
+    for idx, M, v in (((0, 1), np.array([[1.7, -0.2], [2.3, 1.2]]), np.array([5.4, -3.4])),
+                      ((1, 2), np.array([[-5.0, 3.3], [9.1, 1.9]]), np.array([-3.3, 4.4])),
+                      ((0, 3), np.array([[0.2, -0.5], [1.1, -3.1]]), np.array([0.5, 0.0]))):
+        J = np.zeros((2, 4)); J[:, list(idx)] = M
+        G += J.T @ J; c += J.T @ (-v)
+    Aeq = np.zeros((2, 4)); Aeq[:, [1, 3]] = np.array([[1.1, -1.1], [0.3, 0.6]])
+    k2 = dict(name="nullspace2", G=G, c=c, A_eq=Aeq, b_eq=-np.array([1.3, -4.0]),
+              expected=[(1, -3.656565656565657, 1e-14), (3, -4.838383838383838, 1e-14), (0, -0.707724112814252, 1e-13),
+                        (2, 0.0247370254266801, 1e-13)])
+    return [k1, k2]

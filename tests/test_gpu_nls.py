@@ -174,3 +174,45 @@ def test_nls_argument_errors_and_callback_failure():
     bad = NLS.Problem(2, lambda x, w: (_ for _ in ()).throw(ValueError("boom")), cost_rows=2)
     with pytest.raises(ValueError):
         NLS.ConstrainedNonlinearLeastSquares(bad, batch=3).Solve(NLS.Params(), T(np.zeros((3, 2))))
+
+
+def test_null_space_solver():
+    """mo_nullspace_solve (row f4): the reference's two known-answer problems (qp_test.cc:576-707), a random batch against the
+    oracle's QR / Cholesky restatement (qp.cc:679-729), and NOT_POSITIVE_DEFINITE on an indefinite reduced Hessian."""
+    for kat in P.nullspace_kats():
+        n, k = kat["G"].shape[0], kat["A_eq"].shape[0]
+        prob = Q.BatchedQP(n=n, k=k, G=T(np.tril(kat["G"]).T[None]), c=T(kat["c"][None]), A_eq=T(kat["A_eq"].T[None]),
+                           b_eq=T(kat["b_eq"][None]))
+        s = Q.QPNullSpaceSolver()
+        term = s.Solve(prob)
+        assert int(term[0]) == Q.QPNullSpaceSolver.SUCCESS
+        x = s.variables().cpu().numpy()[0]
+        for idx, val, tol in kat["expected"]:
+            assert abs(x[idx] - val) <= max(tol, 1e-13), (kat["name"], idx, x[idx], val)
+    rng = np.random.default_rng(3)
+    B, n, k, m_r = 64, 24, 5, 40
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, k, n)); b = rng.uniform(-1, 1, (B, k))
+    G = np.einsum("bqi,bqj->bij", J, J); c = np.einsum("bqi,bq->bi", J, r)
+    G[7] = -G[7]                                                   # negative definite -> NOT_POSITIVE_DEFINITE
+    G[9, 0, 0] = G[9, 0, 0] - 1e3                                  # indefinite with a large negative direction
+    prob = Q.BatchedQP(n=n, k=k, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), A_eq=T(A.transpose(0, 2, 1)), b_eq=T(b))
+    s = Q.QPNullSpaceSolver()
+    term = s.Solve(prob).cpu().numpy()
+    x = s.variables().cpu().numpy()
+    for p in range(B):
+        ok, xr = N.null_space_solve(N.QPData(np.tril(G[p]), c[p], A[p], b[p], []))
+        assert (term[p] == 0) == ok, p
+        if ok:
+            np.testing.assert_allclose(x[p], xr, rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(A[p] @ x[p] + b[p], 0, atol=1e-11)
+        else:
+            assert np.all(np.isnan(x[p]))
+    assert term[7] == 1 and term[9] == 1 and term.sum() == 2
+    # J-level input gives the same answers
+    probJ = Q.BatchedQP(n=n, k=k, J=T(J), r=T(r), A_eq=T(A.transpose(0, 2, 1)), b_eq=T(b))
+    sJ = Q.QPNullSpaceSolver()
+    tJ = sJ.Solve(probJ).cpu().numpy()
+    good = [p for p in range(B) if p not in (7, 9)]
+    assert np.all(tJ == 0)
+    np.testing.assert_allclose(sJ.variables().cpu().numpy()[good], x[good], rtol=1e-9, atol=1e-11)

@@ -109,3 +109,16 @@ def test_sphere_with_nonlinear_equality_constraints():
         best = min(P.SPHERE_SOLUTIONS, key=lambda s: np.linalg.norm(np.array(s) - nls.variables))
         np.testing.assert_allclose(nls.variables, best, atol=5e-5, err_msg=str(guess))
         assert all(l.step_result not in (N.STEP_MAX_ITERATIONS, N.STEP_POSITIVE_DERIVATIVE) for l in logs)   # no failed line searches
+
+
+# ---- QPNullSpaceSolver known answers, qp_test.cc:576-707 (problem data restated in tests/nls_problems.py)
+def test_null_space_solver_kats():
+    for kat in P.nullspace_kats():
+        ok, x = N.null_space_solve(N.QPData(np.tril(kat["G"]), kat["c"], kat["A_eq"], kat["b_eq"], []))
+        assert ok
+        for idx, val, tol in kat["expected"]:
+            assert abs(x[idx] - val) <= tol, (kat["name"], idx, x[idx], val)
+    # an indefinite reduced Hessian is reported, qp.cc:709-713
+    G = np.diag([1.0, -2.0, 3.0])
+    ok, _ = N.null_space_solve(N.QPData(G, np.zeros(3), np.array([[1.0, 0.0, 0.0]]), np.array([0.5]), []))
+    assert not ok
