@@ -286,6 +286,13 @@ template <unsigned long long MASK> __device__ inline void masked_set(double& dst
                : [d] "+v"(dst), [sv] "=&s"(save)
                : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
+template <unsigned long long MASK> __device__ inline void masked_set_neg(double& dst, double src) {  // dst = -src in the lanes of MASK
+  unsigned long long save;  // v_max_f64 with both operands negated: the negation rides on the source modifiers (no xor + mov)
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_max_f64 %[d], -%[s], -%[s]\n\t"
+               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               : [d] "+v"(dst), [sv] "=&s"(save)
+               : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
+}
 template <unsigned long long MASK> __device__ inline void masked_zero4(d4& T) {  // T[0..3] = 0 in the lanes of MASK
   unsigned long long save;
   double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
@@ -310,7 +317,7 @@ __device__ inline void sweep_step_lean(d4& T, double& bad, int g, int j) {
   inv = fma(inv, fma(-d, inv, 1.0), inv);  // one Newton step: |inv d - 1| < 2e-15 (tools/microbench.hip)
   asm volatile("v_fma_f64 %0, %1, 0, %0" : "+v"(bad) : "v"(inv));  // volatile: hipcc would sink sixteen of these to the end
   double rk = bpermute_f64((16 * src_g + j) * 4, rowreg) * inv;  // T(k, j) / d for this lane's column j, in every row
-  masked_set<mcol>(rk, -inv);
+  masked_set_neg<mcol>(rk, inv);
   double f[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)  // T(g + 4t, k): column k of this lane's own rows ( = T(k, g + 4t) by symmetry when BPF)
