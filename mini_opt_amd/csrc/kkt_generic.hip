@@ -40,7 +40,11 @@
 namespace mo {
 namespace {
 
-constexpr int kThreads = 256;
+// Workgroup size is chosen at launch: 256 threads (4 waves) for large systems, ONE wave for small ones (n + k <= 32), where a
+// 256-thread workgroup would idle on P-long loops and up to 32 single-wave workgroups fit a CU instead of 8.
+constexpr int kMaxThreads = 256;
+#define kThreads ((int)blockDim.x)
+#define kWaves ((int)(blockDim.x >> 6))
 
 template <typename T> struct Ws {
   T* H; int ldh;
@@ -164,7 +168,7 @@ __device__ void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J
     for (int idx = tid; idx < rows; idx += kThreads) w.rc[idx] = r[q0 + idx];
     __syncthreads();
     // each wave owns groups of 4 columns; lanes own rows i >= j0
-    for (int j0 = wave * 4; j0 < n; j0 += 16) {
+    for (int j0 = wave * 4; j0 < n; j0 += 4 * kWaves) {
       const int jc0 = j0, jc1 = (j0 + 1 < n) ? j0 + 1 : n - 1, jc2 = (j0 + 2 < n) ? j0 + 2 : n - 1,
                 jc3 = (j0 + 3 < n) ? j0 + 3 : n - 1;
       for (int i0 = j0; i0 < n; i0 += 64) {
@@ -312,7 +316,7 @@ __device__ int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool inc
     if (found_zero) return MO_STATUS_FACTORIZATION_FAILED;  // non-zero pivot after a zero pivot
     const T inv = (T)1 / d;
     if (tid == 0) w.invd[kk] = inv;
-    for (int j = kk + 1 + wave; j < P; j += 4) {
+    for (int j = kk + 1 + wave; j < P; j += kWaves) {
       const T wj = colk[j] * inv;
       T* colj = w.H + (size_t)j * w.ldh;
       for (int i = j + lane; i < P; i += 64) colj[i] -= colk[i] * wj;
@@ -470,7 +474,7 @@ __device__ void update_state(const Ws<T>& w, int n, int k, int m, T ap, T ad, in
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
 template <typename T, int MODE>
-__global__ __launch_bounds__(kThreads) void kkt_generic_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ws<T> w;
   const int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
@@ -728,9 +732,11 @@ size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
 hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
   const int elem = dtype == MO_F64 ? 8 : 4;
   const size_t lds = generic_lds_bytes(a, elem);
+  const int threads = (a.n + a.k <= 32) ? 64 : kMaxThreads;
+  const int max_per_cu = threads == 64 ? 32 : 8;
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
+  if (per_cu > max_per_cu) per_cu = max_per_cu;
   long long grid = (long long)num_cus * per_cu;
   if (grid > a.batch) grid = a.batch;
   if (grid < 1) grid = 1;
@@ -740,7 +746,7 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
     e = hipFuncSetAttribute((const void*)kkt_generic_kernel<TYPE, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)lds);                                                                               \
     if (e != hipSuccess) return e;                                                                                   \
-    hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_>), dim3((unsigned)grid), dim3(kThreads), lds, stream, a);     \
+    hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_>), dim3((unsigned)grid), dim3(threads), lds, stream, a);     \
   } while (0)
 #define MO_DISPATCH_MODE(TYPE)                                          \
   switch (a.mode) {                                                     \
