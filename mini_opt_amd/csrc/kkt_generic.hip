@@ -20,6 +20,8 @@
 // followed by the state, residual, direction, rhs and constraint vectors and a small row-chunk of J.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "mo_kernels.h"
 
 // Phase stamps exist only in the diagnostic build of tools/phase_timer_generic.hip; the product kernel executes none.
@@ -40,7 +42,7 @@
 namespace mo {
 namespace {
 
-// Workgroup size is chosen at launch: 256 threads (4 waves) for large systems, ONE wave for small ones (n + k <= 32), where a
+// Workgroup size is chosen at launch: 256 threads (4 waves) for large systems, ONE wave for small ones (n + k <= 48), where a
 // 256-thread workgroup would idle on P-long loops and up to 32 single-wave workgroups fit a CU instead of 8.
 constexpr int kMaxThreads = 256;
 #define kThreads ((int)blockDim.x)
@@ -732,8 +734,10 @@ size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
 hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
   const int elem = dtype == MO_F64 ? 8 : 4;
   const size_t lds = generic_lds_bytes(a, elem);
-  const int threads = (a.n + a.k <= 32) ? 64 : kMaxThreads;
-  const int max_per_cu = threads == 64 ? 32 : 8;
+  static const int env_threads = [] { const char* e = getenv("MO_GENERIC_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob
+  int threads = (a.n + a.k <= 48) ? 64 : kMaxThreads;  // measured: cfg 2 (P = 36) 8.5 M vs 6.8 M steps/s, cfg 3 (P = 72) 0.75 M vs 1.9 M
+  if (env_threads == 64 || env_threads == 128 || env_threads == 256) threads = env_threads;
+  const int max_per_cu = 32 / (threads / 64);
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > max_per_cu) per_cu = max_per_cu;
