@@ -98,6 +98,8 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
   const bool force_generic = (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
   if (!force_generic && mo::fused_supported(a, plan->desc.dtype)) {
     MO_HIP_CHECK(mo::launch_fused(a, plan->desc.dtype, plan->num_cus, s));
+  } else if (!force_generic && mo::fused_f32_supported(a, plan->desc.dtype)) {
+    MO_HIP_CHECK(mo::launch_fused_f32(a, plan->num_cus, s));
   } else {
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
@@ -211,6 +213,7 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned state / output
   a.ticket = plan->ticket;
   if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype)) return mo::fused_name(a, plan->desc.dtype);
+  if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_f32_supported(a, plan->desc.dtype)) return mo::fused_f32_name(a);
   return "generic";
 }
 

@@ -68,6 +68,11 @@ const char* fused_name(const KernelArgs& a, int dtype);
 hipError_t launch_fused(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
 
 
+// fused single-wave fp32 step kernel for n = 64 / 128 (J-level input), kkt_fused_f32.hip
+bool fused_f32_supported(const KernelArgs& a, int dtype);
+const char* fused_f32_name(const KernelArgs& a);
+hipError_t launch_fused_f32(const KernelArgs& a, int num_cus, hipStream_t stream);
+
 // small per-problem kernels around the QP (LinearizeAndFillQP tail, EvaluateNonlinearErrors, ComputeQPCostDerivative), nls_kernels.hip
 struct AuxArgs {
   int n, k, m, m_r;
