@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 = 32 cycles
 FP64_PEAK_TFLOPS = 78.6  # datasheet fp64 matrix = vector rate; tools/microbench.hip measures 64 cycles per v_mfma_f64_16x16x4_f64
 
 
@@ -153,6 +154,12 @@ def main():
                          "fp64_frac_of_peak": synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "status_ok": ok, "status_total": batch,
         }
+        if cfg["dtype"] == "f32":  # cfg 4 is bound by the fp32 matrix cores (AI 37.5 flop/B vs ridge 19.7), not by HBM
+            tf = synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "algorithmic_flops_per_step": synth.algorithmic_flops(n, k, m, m_r), "kernel_ms": kernel_ms,
+                               "hbm_gbs_algorithmic": achieved}
 
         # parity gate on a sample (oracle = checker only)
         try:

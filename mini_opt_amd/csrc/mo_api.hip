@@ -210,7 +210,8 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   mo::KernelArgs a;
   if (fill_problem(plan, prob, 1, true, true, &a) != MO_OK) return "invalid";
   a.mode = mo::MODE_STEP;
-  a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned state / output
+  a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned, densely packed state / output
+  a.vars_stride = a.delta_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
   a.ticket = plan->ticket;
   if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype)) return mo::fused_name(a, plan->desc.dtype);
   if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_f32_supported(a, plan->desc.dtype)) return mo::fused_f32_name(a);

@@ -500,3 +500,64 @@ def test_fused_qp_level_step_and_solve(cfg):
         term, its = o.solve(**kw)
         assert int(out.termination_state[p]) == term and int(out.num_iterations[p]) == len(its)
         np.testing.assert_allclose(v[p], o.variables, rtol=1e-7, atol=1e-9)
+
+
+# ------------------------------------------------------------------ fused fp32 kernel (BASELINE configs[3] and neighbours)
+@pytest.mark.parametrize("n,k,m,m_r", [(128, 16, 64, 256), (128, 0, 0, 8), (128, 16, 3, 132), (128, 5, 64, 4), (64, 8, 32, 128),
+                                       (64, 16, 0, 64), (64, 0, 17, 260)])
+def test_fused_f32_shapes(n, k, m, m_r):
+    """The fp32 MFMA kernel (kkt_fused_f32.hip): cfg 4 itself, k = 16 (a full y tile) and k = 0, m = 64 and m = 0, tiny and ragged
+    m_r, duplicated constraint variables, the n = 64 instantiation -- against the fp64 oracle on fp32-rounded inputs (no
+    reference counterpart exists for fp32; tolerance 2e-3 rel-inf as for the generic kernel, observed ~1e-6)."""
+    rng = np.random.default_rng(n * 1000 + k * 100 + m + m_r)
+    B = 19
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    J = f(rng.uniform(-1, 1, (B, m_r, n))); r = f(rng.uniform(-1, 1, (B, m_r)))
+    A = f(rng.uniform(-1, 1, (B, n, k))); b = f(rng.uniform(-1, 1, (B, k)))
+    cv = rng.integers(0, min(n, 7), (B, m)).astype(np.int32)
+    ca = rng.choice([-1.0, 1.0, 2.5], (B, m)); cb = f(rng.uniform(0.5, 2.0, (B, m)))
+    x = f(rng.uniform(-0.1, 0.1, (B, n)))
+    sl = f(rng.uniform(0.2, 1.5, (B, m))); z = f(rng.uniform(0.1, 2, (B, m))); y = f(rng.uniform(-1, 1, (B, k)))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    V = vars_.shape[1]
+    pad = (-V) % 4                                                  # the kernel stores dx with 16-byte stores: stride % 4 == 0
+    mu = np.full(B, float(np.float32(0.05)))
+    lam = float(np.float32(0.5 if m_r < n else 1e-3))
+    dt = torch.float32
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J, dt), r=T(r, dt), lam=lam, A_eq=T(A, dt) if k else None, b_eq=T(b, dt) if k else None,
+                       cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca, dt) if m else None, cons_b=T(cb, dt) if m else None)
+    s = Q.QPInteriorPointSolver(prob)
+    if pad:
+        assert s.step_kernel() == "generic"                         # V % 4 != 0: the library falls back to the generic kernel
+        return
+    assert s.step_kernel().startswith("fused_mfma_f32"), s.step_kernel()
+    s.SetVariables(T(vars_, dt))
+    delta, alpha, status = s.NewtonStep(T(mu, dt), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
+        n, k, m, J=J, r=r, lam=lam, A_eq=A if k else None, b_eq=b if k else None, cons_var=cv if m else None,
+        cons_a=ca if m else None, cons_b=cb if m else None, vars_=vars_, mu=mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    err = rel_inf_rows(delta.double().cpu().numpy(), ref)
+    assert err.max() < TOL32, err.max()
+    np.testing.assert_allclose(alpha.double().cpu().numpy(), ref_alpha, atol=5e-3)
+
+
+def test_fused_f32_status_words():
+    d = synth.CONFIGS["cfg4"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 12, stream=4)
+    n = hb.n
+    hb.vars[1, n] = 0.0
+    hb.cons_var[4, 0] = n + 7
+    hb.J[5, 3, 2] = np.nan
+    hb.cons_var[6, 1] = -1
+    s = Q.QPInteriorPointSolver(batch_to_device(hb, torch.float32))
+    assert s.step_kernel() == "fused_mfma_f32_n128"
+    s.SetVariables(T(hb.vars, torch.float32))
+    delta, alpha, status = s.NewtonStep(T(hb.mu, torch.float32), 0.995)
+    st = status.cpu().numpy()
+    good = [0, 2, 3, 7, 8, 9, 10, 11]
+    assert np.all(st[good] == 0)
+    assert st[1] == L.MO_STATUS_NONPOSITIVE_SLACK and st[4] == L.MO_STATUS_BAD_INDEX and st[6] == L.MO_STATUS_BAD_INDEX
+    assert st[5] in (L.MO_STATUS_NONFINITE, L.MO_STATUS_FACTORIZATION_FAILED)
+    dn = delta.cpu().numpy()
+    assert np.all(np.isnan(dn[[1, 4, 5, 6]])) and np.all(np.isfinite(dn[good]))
