@@ -115,3 +115,34 @@ def test_full_batch_solve_reaches_kkt_point(cfg, batch):
     w = worst.cpu().numpy()
     assert w[0] < 1e-8 and w[1] < 1e-8 and w[2] < 1e-8 and w[3] < 1e-4, w   # complementarity tolerance 1e-6 on the mean
     assert bool((z >= 0).all()) and bool((s > 0).all())
+
+
+def test_full_batch_fp32_cfg4_satisfies_newton_equations():
+    """BASELINE configs[3] at its full batch through the fused fp32 kernel: every problem satisfies the reduced KKT Newton equations
+    evaluated in fp64 on the fp32 inputs (relative residual at fp32 rounding level), launches are bit-identical, and a sample agrees
+    with the fp64 oracle within the fp32 tolerance."""
+    d = synth.CONFIGS["cfg4"]
+    dev = torch.device("cuda:0")
+    batch = d["batch"]
+    prob, vars_, mu = synth.make_batch_torch(d["n"], d["k"], d["m"], d["m_r"], batch, dev, torch.float32, seed=4321)
+    solver = Q.QPInteriorPointSolver(prob)
+    assert solver.step_kernel() == "fused_mfma_f32_n128"
+    solver.SetVariables(vars_)
+    delta, alpha, status = solver.NewtonStep(mu, 0.995)
+    d1, a1 = delta.clone(), alpha.clone()
+    assert int((status != 0).sum()) == 0
+    assert torch.isfinite(delta).all() and torch.isfinite(alpha).all()
+    errs = newton_equation_residuals(prob, vars_, mu, d1, chunk=4096)
+    assert errs.max() < 2e-4, errs                                 # fp32 arithmetic: ~cond * 6e-8
+    assert (alpha > 0).all() and (alpha <= 1).all()
+    delta2, alpha2, _ = solver.NewtonStep(mu, 0.995)
+    assert torch.equal(delta2, d1) and torch.equal(alpha2, a1)
+    n, k, m = d["n"], d["k"], d["m"]
+    idx = torch.arange(0, batch, batch // 96, device=dev)
+    h = lambda t: t.index_select(0, idx).double().cpu().numpy()
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
+        n, k, m, J=h(prob.J), r=h(prob.r), lam=float(np.float32(prob.lam)), A_eq=h(prob.A_eq), b_eq=h(prob.b_eq),
+        cons_var=prob.cons_var.index_select(0, idx).cpu().numpy(), cons_a=h(prob.cons_a), cons_b=h(prob.cons_b), vars_=h(vars_), mu=h(mu))
+    got = h(d1)
+    err = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
+    assert err.max() < 2e-3, err.max()
