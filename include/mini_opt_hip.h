@@ -291,6 +291,19 @@ void mo_default_nls_params(mo_nls_params* params);
 int mo_nls_solve(mo_plan* plan, const mo_nls_problem* prob, int64_t batch, const mo_nls_params* params, mo_nls_eval_fn eval,
                  void* user, int32_t* termination, int32_t* num_iterations, void* iterations, int32_t* status, void* stream);
 
+/* Device residual families: the residual functions of the reference's own NLS tests as kernels (its Residual functors are host
+ * lambdas, residual.hpp:28-143), so that an mo_nls_solve callback can be two launches instead of a PCIe round trip.
+ *   ROSENBROCK     n >= 2, rows = 2 (n - 1): r_2i = 1 - x_i, r_2i+1 = 10 (x_i+1 - x_i^2)     (nonlinear_test.cc:375-386, 502-521)
+ *   HIMMELBLAU     n = 2, rows = 2: x^2 + y - 11, x + y^2 - 7                                  (nonlinear_test.cc:578-593)
+ *   SPHERE         rows = n: r = x                                                             (nonlinear_test.cc:722-730)
+ *   PRODUCT_PAIRS  rows <= n / 2: r_q = x_2q x_2q+1 - params[q]  (params: `rows` device scalars) (nonlinear_test.cc:737-743)
+ * r [batch][rows]; J (NULL = values only) dense rows x n per problem, row-major (cost stacks) or column-major (equality stacks,
+ * = QP::A_eq), zeros written. */
+typedef enum { MO_RESIDUAL_ROSENBROCK = 0, MO_RESIDUAL_HIMMELBLAU = 1, MO_RESIDUAL_SPHERE = 2, MO_RESIDUAL_PRODUCT_PAIRS = 3 } mo_residual_family;
+int mo_residual_eval(mo_plan* plan, int32_t family, int32_t rows, const void* params, const void* x, int64_t x_stride,
+                     int64_t batch, void* r, int64_t r_stride, void* J, int64_t J_stride, int32_t J_ld, int32_t J_layout,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

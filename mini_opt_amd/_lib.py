@@ -25,7 +25,7 @@ MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
 EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
            "mo_plan_destroy", "mo_plan_step_kernel", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
            "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative",
-           "mo_default_nls_params", "mo_nls_solve", "mo_nullspace_solve"]
+           "mo_default_nls_params", "mo_nls_solve", "mo_nullspace_solve", "mo_residual_eval"]
 
 
 class PlanDesc(C.Structure):
@@ -77,6 +77,7 @@ class NlsProblem(C.Structure):
 NLS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
 MO_NLS_EVAL_LINEARIZE, MO_NLS_EVAL_ERRORS = 0, 1
 MO_NLS_ITER_HEADER = 12
+MO_RESIDUAL_ROSENBROCK, MO_RESIDUAL_HIMMELBLAU, MO_RESIDUAL_SPHERE, MO_RESIDUAL_PRODUCT_PAIRS = range(4)
 
 
 def build(force: bool = False) -> str:
@@ -122,6 +123,7 @@ def lib() -> C.CDLL:
     L.mo_nonlinear_errors.argtypes = [vp, vp, i64, vp, i64, i64, vp, vp]
     L.mo_qp_cost_derivative.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp, vp]
     L.mo_nullspace_solve.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp]
+    L.mo_residual_eval.argtypes = [vp, i32, i32, vp, vp, i64, i64, vp, i64, vp, i64, i32, i32, vp]
     L.mo_default_nls_params.argtypes = [C.POINTER(NlsParams)]
     L.mo_default_nls_params.restype = None
     L.mo_nls_solve.argtypes = [vp, C.POINTER(NlsProblem), i64, C.POINTER(NlsParams), NLS_EVAL_FN, vp, vp, vp, vp, vp, vp]

@@ -598,4 +598,26 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
   return MO_OK;
 }
 
+int mo_residual_eval(mo_plan* plan, int32_t family, int32_t rows, const void* params, const void* x, int64_t x_stride,
+                     int64_t batch, void* r, int64_t r_stride, void* J, int64_t J_stride, int32_t J_ld, int32_t J_layout,
+                     void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  const mo_plan_desc& d = plan->desc;
+  if (batch < 0) return fail(MO_ERR_INVALID_ARGUMENT, "batch must be >= 0");
+  if (!x || !r) return fail(MO_ERR_INVALID_ARGUMENT, "x / r is NULL");
+  const int want = mo::residual_family_rows(family, d.n, rows);
+  if (want < 0 || want != rows) return fail(MO_ERR_DIMENSION, "residual family %d with n = %d has %d rows, not %d", family, d.n, want, rows);
+  if (family == MO_RESIDUAL_PRODUCT_PAIRS && !params) return fail(MO_ERR_INVALID_ARGUMENT, "PRODUCT_PAIRS needs params");
+  if (J) {
+    if (J_layout != MO_ROW_MAJOR && J_layout != MO_COL_MAJOR) return fail(MO_ERR_INVALID_ARGUMENT, "bad J_layout");
+    const int min_ld = J_layout == MO_ROW_MAJOR ? d.n : rows;
+    if (J_ld < min_ld) return fail(MO_ERR_DIMENSION, "J_ld %d < %d", J_ld, min_ld);
+  }
+  MO_HIP_CHECK(hipSetDevice(d.device));
+  MO_HIP_CHECK(mo::launch_residual_family(family, d.n, rows, batch, d.dtype, params, x, x_stride, r, r_stride, J, J_stride, J_ld,
+                                          J_layout == MO_ROW_MAJOR, (hipStream_t)stream));
+  return MO_OK;
+}
+
 }  // extern "C"

@@ -119,6 +119,11 @@ struct NlsArgs {
   int* termination; int* num_iterations; int* status;
   int* counters;                                    // [0] problems still in the line search, [1] problems still active
 };
+// device residual families (nls_kernels.hip); rows = -1 if (family, n, rows_hint) is not a valid combination
+int residual_family_rows(int family, int n, int rows_hint);
+hipError_t launch_residual_family(int family, int n, int rows, long long batch, int dtype, const void* prm, const void* x,
+                                  long long x_stride, void* r, long long r_stride, void* J, long long J_stride, int J_ld,
+                                  int row_major, hipStream_t stream);
 hipError_t launch_nls_init(const NlsArgs& a, hipStream_t stream);
 hipError_t launch_nls_begin_search(const NlsArgs& a, hipStream_t stream);
 hipError_t launch_nls_search_step(const NlsArgs& a, hipStream_t stream);

@@ -339,3 +339,94 @@ hipError_t launch_nls_update(const NlsArgs& a, hipStream_t stream) {
 }
 
 }  // namespace mo
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device residual families: the residual functions of the reference's own NLS tests as kernels, so that a
+// caller's mo_nls_solve callback can be two launches instead of a PCIe round trip.  One thread per (problem, residual row);
+// J is written dense (row-major m_r x n, or column-major rows x n for equality stacks = QP::A_eq), zeros included.
+namespace mo {
+namespace {
+
+template <typename T> __device__ inline void put(T* J, int row, int col, int rows, int ld, bool row_major, T v) {
+  J[row_major ? (size_t)row * ld + col : (size_t)col * ld + row] = v;
+  (void)rows;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void residual_family_kernel(int family, int n, int rows, long long batch, const T* prm, const T* x,
+                                                              long long x_stride, T* r, long long r_stride, T* J, long long J_stride,
+                                                              int J_ld, int row_major) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= batch * rows) return;
+  const long long p = idx / rows;
+  const int q = (int)(idx - p * rows);
+  const T* xp = x + p * x_stride;
+  T* Jp = J ? J + p * J_stride : nullptr;
+  if (Jp)
+    for (int c = 0; c < n; ++c) put(Jp, q, c, rows, J_ld, row_major != 0, (T)0);
+  T val = 0;
+  switch (family) {
+    case MO_RESIDUAL_ROSENBROCK: {  // nonlinear_test.cc:375-386 (n = 2), 502-521 (chain): rows 2i, 2i+1 for i < n-1
+      const int i = q >> 1;
+      if (q & 1) {
+        val = (T)10 * (xp[i + 1] - xp[i] * xp[i]);
+        if (Jp) { put(Jp, q, i, rows, J_ld, row_major != 0, (T)-20 * xp[i]); put(Jp, q, i + 1, rows, J_ld, row_major != 0, (T)10); }
+      } else {
+        val = (T)1 - xp[i];
+        if (Jp) put(Jp, q, i, rows, J_ld, row_major != 0, (T)-1);
+      }
+      break;
+    }
+    case MO_RESIDUAL_HIMMELBLAU: {  // nonlinear_test.cc:578-593
+      if (q == 0) {
+        val = xp[0] * xp[0] + xp[1] - (T)11;
+        if (Jp) { put(Jp, 0, 0, rows, J_ld, row_major != 0, (T)2 * xp[0]); put(Jp, 0, 1, rows, J_ld, row_major != 0, (T)1); }
+      } else {
+        val = xp[0] + xp[1] * xp[1] - (T)7;
+        if (Jp) { put(Jp, 1, 0, rows, J_ld, row_major != 0, (T)1); put(Jp, 1, 1, rows, J_ld, row_major != 0, (T)2 * xp[1]); }
+      }
+      break;
+    }
+    case MO_RESIDUAL_SPHERE: {      // nonlinear_test.cc:722-730: h(x) = x
+      val = xp[q];
+      if (Jp) put(Jp, q, q, rows, J_ld, row_major != 0, (T)1);
+      break;
+    }
+    case MO_RESIDUAL_PRODUCT_PAIRS: {  // nonlinear_test.cc:737-743: x_{2q} x_{2q+1} - v_q
+      val = xp[2 * q] * xp[2 * q + 1] - prm[q];
+      if (Jp) { put(Jp, q, 2 * q, rows, J_ld, row_major != 0, xp[2 * q + 1]); put(Jp, q, 2 * q + 1, rows, J_ld, row_major != 0, xp[2 * q]); }
+      break;
+    }
+    default: break;
+  }
+  r[p * r_stride + q] = val;
+}
+
+}  // namespace
+
+int residual_family_rows(int family, int n, int rows_hint) {
+  switch (family) {
+    case MO_RESIDUAL_ROSENBROCK: return n >= 2 ? 2 * (n - 1) : -1;
+    case MO_RESIDUAL_HIMMELBLAU: return n == 2 ? 2 : -1;
+    case MO_RESIDUAL_SPHERE: return n;
+    case MO_RESIDUAL_PRODUCT_PAIRS: return (rows_hint >= 1 && 2 * rows_hint <= n) ? rows_hint : -1;
+    default: return -1;
+  }
+}
+
+hipError_t launch_residual_family(int family, int n, int rows, long long batch, int dtype, const void* prm, const void* x,
+                                  long long x_stride, void* r, long long r_stride, void* J, long long J_stride, int J_ld,
+                                  int row_major, hipStream_t stream) {
+  if (batch <= 0 || rows <= 0) return hipSuccess;
+  const long long total = batch * rows;
+  const dim3 gd((unsigned)((total + 255) / 256)), bd(256);
+  if (dtype == MO_F64)
+    hipLaunchKernelGGL(residual_family_kernel<double>, gd, bd, 0, stream, family, n, rows, batch, (const double*)prm, (const double*)x,
+                       x_stride, (double*)r, r_stride, (double*)J, J_stride, J_ld, row_major);
+  else
+    hipLaunchKernelGGL(residual_family_kernel<float>, gd, bd, 0, stream, family, n, rows, batch, (const float*)prm, (const float*)x,
+                       x_stride, (float*)r, r_stride, (float*)J, J_stride, J_ld, row_major);
+  return hipGetLastError();
+}
+
+}  // namespace mo

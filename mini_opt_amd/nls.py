@@ -71,6 +71,32 @@ class Params:
 
 ResidualFn = Callable[[torch.Tensor, bool], Tuple[torch.Tensor, Optional[torch.Tensor]]]
 
+ROSENBROCK, HIMMELBLAU, SPHERE, PRODUCT_PAIRS = range(4)  # mo_residual_family
+
+
+@dataclass
+class DeviceFamily:
+    """One of the library's device residual families (mo_residual_eval): evaluated by a HIP kernel straight into the solver's
+    buffers -- no torch ops, no copies.  `params`: device tensor of family parameters (PRODUCT_PAIRS: the products v_q)."""
+    family: int
+    rows: int
+    params: Optional[torch.Tensor] = None
+
+    def eval_into(self, plan, x: torch.Tensor, r: torch.Tensor, J: Optional[torch.Tensor], n: int, row_major: bool) -> None:
+        B = int(x.shape[0])
+        L.check(L.lib().mo_residual_eval(plan.h, self.family, self.rows, _ptr(self.params), _ptr(x), int(x.stride(0)), B, _ptr(r),
+                                         self.rows, _ptr(J), self.rows * n, n if row_major else self.rows,
+                                         L.MO_ROW_MAJOR if row_major else L.MO_COL_MAJOR, _stream()))
+
+    def __call__(self, x: torch.Tensor, want_J: bool):
+        """The ResidualFn contract, for use outside mo_nls_solve (returns J as [B, rows, n])."""
+        B, n = int(x.shape[0]), int(x.shape[1])
+        plan = _Plan(n, 0, 0, max(self.rows, 1), x.dtype, x.device, B)
+        r = torch.empty(B, self.rows, dtype=x.dtype, device=x.device)
+        J = torch.empty(B, self.rows, n, dtype=x.dtype, device=x.device) if want_J else None
+        self.eval_into(plan, x.contiguous(), r, J, n, True)
+        return r, J
+
 
 @dataclass
 class Problem:
@@ -146,18 +172,25 @@ class ConstrainedNonlinearLeastSquares:
     # ---- callbacks: enqueue the user's residual evaluation on the stream the library works on
     def _eval(self, user, what, stream):
         try:
-            if what == L.MO_NLS_EVAL_LINEARIZE:
-                r, J = self.p_.cost(self.variables_, True)
-                self.r.copy_(r); self.J.copy_(J)
-                if self.k:
-                    r_eq, J_eq = self.p_.equality(self.variables_, True)
-                    self.r_eq.copy_(r_eq); self.J_eq.copy_(J_eq.transpose(1, 2))
+            lin = what == L.MO_NLS_EVAL_LINEARIZE
+            x = self.variables_ if lin else self.candidate_vars_
+            r_buf = self.r if lin else self.r_cand
+            if isinstance(self.p_.cost, DeviceFamily):          # a HIP kernel writes the solver's buffers directly
+                self.p_.cost.eval_into(self._plan, x, r_buf, self.J if lin else None, self.n, True)
             else:
-                r, _ = self.p_.cost(self.candidate_vars_, False)
-                self.r_cand.copy_(r)
-                if self.k:
-                    r_eq, _ = self.p_.equality(self.candidate_vars_, False)
-                    self.r_eq_cand.copy_(r_eq)
+                r, J = self.p_.cost(x, lin)
+                r_buf.copy_(r)
+                if lin:
+                    self.J.copy_(J)
+            if self.k:
+                req_buf = self.r_eq if lin else self.r_eq_cand
+                if isinstance(self.p_.equality, DeviceFamily):
+                    self.p_.equality.eval_into(self._plan, x, req_buf, self.J_eq if lin else None, self.n, False)  # k x n col-major
+                else:
+                    r_eq, J_eq = self.p_.equality(x, lin)
+                    req_buf.copy_(r_eq)
+                    if lin:
+                        self.J_eq.copy_(J_eq.transpose(1, 2))
             return 0
         except Exception as e:  # an exception must not unwind through the C frames
             self._callback_error = e

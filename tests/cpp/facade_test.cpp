@@ -202,6 +202,53 @@ static void TestNlsSphereWithEqualities() {
   }
 }
 
+// The C ABI alone: mo_nls_solve with a callback that only launches the library's device residual kernels (mo_residual_eval) --
+// the Himmelblau sweep of nonlinear_test.cc:597-664 without a single host-side residual evaluation.
+struct HimmelblauCtx { mo_plan* plan; double *vars, *cand, *J, *r, *r_cand; int64_t batch; };
+static int HimmelblauEval(void* user, int32_t what, void* stream) {
+  auto* c = static_cast<HimmelblauCtx*>(user);
+  const bool lin = what == MO_NLS_EVAL_LINEARIZE;
+  return mo_residual_eval(c->plan, MO_RESIDUAL_HIMMELBLAU, 2, nullptr, lin ? c->vars : c->cand, 2, c->batch, lin ? c->r : c->r_cand, 2,
+                          lin ? c->J : nullptr, 4, 2, MO_ROW_MAJOR, stream);
+}
+static void TestNlsDeviceResiduals() {
+  std::vector<double> guesses;
+  for (double x = -4.5; x <= 4.5; x += 0.3) for (double y = -4.5; y <= 4.5; y += 0.3) { guesses.push_back(x); guesses.push_back(y); }
+  const int64_t B = (int64_t)guesses.size() / 2;
+  mo_plan_desc d{}; d.n = 2; d.k = 0; d.m = 4; d.m_r = 2; d.dtype = MO_F64; d.device = 0; d.max_batch = B;
+  mo_plan* plan = nullptr;
+  EXPECT_TRUE(mo_plan_create(&d, &plan) == MO_OK);
+  detail::DeviceBuffer<double> vars, cand((size_t)B * 2), J((size_t)B * 4), r((size_t)B * 2), r_cand((size_t)B * 2), ca, cb;
+  detail::DeviceBuffer<int32_t> cv, term((size_t)B);
+  vars.Upload(guesses.data(), guesses.size());
+  const std::vector<int32_t> hv = {0, 0, 1, 1};                       // Var(i) >= -5, Var(i) <= 5
+  const std::vector<double> ha = {1.0, -1.0, 1.0, -1.0}, hb = {5.0, 5.0, 5.0, 5.0};
+  cv.Upload(hv.data(), 4); ca.Upload(ha.data(), 4); cb.Upload(hb.data(), 4);
+  mo_nls_problem np{};
+  np.vars = vars.get(); np.vars_stride = 2; np.candidate = cand.get(); np.candidate_stride = 2;
+  np.J = J.get(); np.J_stride = 4; np.J_ld = 2; np.J_layout = MO_ROW_MAJOR; np.r = r.get(); np.r_stride = 2;
+  np.r_cand = r_cand.get(); np.r_cand_stride = 2;
+  np.cons_var = cv.get(); np.cons_a = ca.get(); np.cons_b = cb.get(); np.cons_stride = 0;
+  mo_nls_params sp; mo_default_nls_params(&sp);
+  sp.max_iterations = 20; sp.max_qp_iterations = 10; sp.relative_exit_tol = 1e-12; sp.absolute_first_derivative_tol = 1e-8;
+  sp.termination_kkt_tolerance = 1e-6;
+  HimmelblauCtx ctx{plan, vars.get(), cand.get(), J.get(), r.get(), r_cand.get(), B};
+  EXPECT_TRUE(mo_nls_solve(plan, &np, B, &sp, HimmelblauEval, &ctx, term.get(), nullptr, nullptr, nullptr, nullptr) == MO_OK);
+  std::vector<double> x((size_t)B * 2); vars.Download(x.data(), x.size());
+  std::vector<int32_t> t((size_t)B); term.Download(t.data(), t.size());
+  const double sols[4][2] = {{3.0, 2.0}, {-2.805118, 3.131312}, {-3.779310, -3.283186}, {3.584428, -1.848126}};
+  int bad = 0;
+  for (int64_t i = 0; i < B; ++i) {
+    double best = 1e9;
+    for (auto& s : sols) best = std::fmin(best, std::hypot(x[2 * i] - s[0], x[2 * i + 1] - s[1]));
+    const bool satisfied = t[i] == MO_NLS_SATISFIED_ABSOLUTE_TOL || t[i] == MO_NLS_SATISFIED_RELATIVE_TOL || t[i] == MO_NLS_SATISFIED_FIRST_ORDER_TOL;
+    if (!satisfied || !(best < 5e-5)) ++bad;
+  }
+  EXPECT_TRUE(bad == 0);
+  EXPECT_TRUE(B == 961);
+  mo_plan_destroy(plan);
+}
+
 int main() {
   TestLinearInequalityConstraint();
   TestEliminationAllConstraints();
@@ -210,6 +257,7 @@ int main() {
   TestErrors();
   TestNlsRosenbrock();
   TestNlsSphereWithEqualities();
+  TestNlsDeviceResiduals();
   if (g_fail) { std::printf("%d FAILURES\n", g_fail); return 1; }
   std::printf("facade_test: all tests passed\n");
   return 0;

@@ -216,3 +216,51 @@ def test_null_space_solver():
     good = [p for p in range(B) if p not in (7, 9)]
     assert np.all(tJ == 0)
     np.testing.assert_allclose(sJ.variables().cpu().numpy()[good], x[good], rtol=1e-9, atol=1e-11)
+
+
+def test_device_residual_families_match_the_torch_definitions():
+    """mo_residual_eval (row f2): values and dense Jacobians of the four families against the torch / numpy definitions of the
+    reference's test residuals."""
+    rng = np.random.default_rng(11)
+    B = 33
+    for fam, n, rows, ref in ((NLS.ROSENBROCK, 2, 2, P.rosenbrock_torch), (NLS.ROSENBROCK, 6, 10, P.rosenbrock6_torch),
+                              (NLS.HIMMELBLAU, 2, 2, P.himmelblau_torch), (NLS.SPHERE, 6, 6, P.sphere_torch)):
+        x = T(rng.uniform(-3, 3, (B, n)))
+        r, J = NLS.DeviceFamily(fam, rows)(x, True)
+        r0, J0 = ref(x, True)
+        np.testing.assert_allclose(r.cpu().numpy(), r0.cpu().numpy(), rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(J.cpu().numpy(), J0.cpu().numpy(), rtol=1e-14, atol=1e-14)
+    x = T(rng.uniform(-3, 3, (B, 6)))
+    r, J = NLS.DeviceFamily(NLS.PRODUCT_PAIRS, 2, params=T(np.array([4.0, 9.0])))(x, True)
+    r0, J0 = P.sphere_eq_torch(x, True)
+    np.testing.assert_allclose(r.cpu().numpy(), r0.cpu().numpy(), rtol=1e-14, atol=1e-14)
+    np.testing.assert_allclose(J.cpu().numpy(), J0.cpu().numpy(), rtol=1e-14, atol=1e-14)
+    from mini_opt_amd import _lib as L
+    with pytest.raises(L.MiniOptError):
+        NLS.DeviceFamily(NLS.HIMMELBLAU, 2)(T(np.zeros((3, 5))), False)          # Himmelblau needs n = 2
+
+
+def test_nls_with_device_residual_families():
+    """The whole SQP loop with library residual kernels in the callback (no torch ops, no copies): same outcomes as with the
+    torch-evaluated residuals, problem by problem."""
+    kw = dict(max_iterations=20, max_qp_iterations=10, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-8,
+              termination_kkt_tolerance=1e-6)
+    g = T(np.array(P.himmelblau_guesses()))
+    cons = P.box(-5.0, 5.0)
+    a = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, P.himmelblau_torch, cost_rows=2, inequality_constraints=cons), batch=len(g))
+    b = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, NLS.DeviceFamily(NLS.HIMMELBLAU, 2), cost_rows=2, inequality_constraints=cons), batch=len(g))
+    oa, ob = a.Solve(NLS.Params(**kw), g), b.Solve(NLS.Params(**kw), g)
+    assert torch.equal(oa.termination_state, ob.termination_state) and torch.equal(oa.num_iterations, ob.num_iterations)
+    np.testing.assert_allclose(a.variables().cpu().numpy(), b.variables().cpu().numpy(), atol=1e-9)
+    # sphere + product equalities: cost and equality stacks both from device kernels
+    kw2 = dict(max_iterations=100, max_qp_iterations=1, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-9,
+               termination_kkt_tolerance=1e-6, lambda_initial=0.001)
+    g2 = T(np.array(P.sphere_guesses(64)))
+    c = NLS.ConstrainedNonlinearLeastSquares(
+        NLS.Problem(6, NLS.DeviceFamily(NLS.SPHERE, 6), cost_rows=6, equality=NLS.DeviceFamily(NLS.PRODUCT_PAIRS, 2, params=T(np.array([4.0, 9.0]))),
+                    equality_rows=2), batch=64)
+    oc = c.Solve(NLS.Params(**kw2), g2)
+    assert bool(NLS.TerminationStateIndicatesSatisfiedTol(oc.termination_state).all())
+    x = c.variables().cpu().numpy()
+    dist = np.min(np.linalg.norm(x[:, None, :] - np.array(P.SPHERE_SOLUTIONS)[None], axis=2), axis=1)
+    assert dist.max() < 5e-5
