@@ -225,6 +225,25 @@ __device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// Scalar-base forms: global address = sbase (wave-uniform, SGPR pair) + voff (per-lane 32-bit byte offset) + IMM; the LDS
+// address is M0 + IMM + 16 * lane (the instruction offset applies to BOTH sides, found the hard way).  The address
+// arithmetic of a stream then lives on the scalar unit; the VALU (which the f64 MFMA shares) sees none of it.
+template <int IMM> __device__ inline void dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM)
+      : "memory");
+}
+__device__ inline void dma4_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 // Same with 4 bytes per lane: LDS byte address lds_dst + 4 * lane.  64 lanes move 32 consecutive doubles.
 __device__ inline void dma4(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -235,10 +254,11 @@ __device__ inline void dma4(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 // `count` consecutive doubles (count <= 64, wave-uniform) from global memory to LDS without touching a VGPR destination.
+// `src` must be wave-uniform.
 __device__ inline void dma_doubles(const double* src, unsigned lds_dst, int count, int lane) {
-  const char* s4 = reinterpret_cast<const char*>(src) + 4 * lane;
-  if (lane < 2 * count) dma4(s4, lds_dst);
-  if (lane + 64 < 2 * count) dma4(s4 + 256, lds_dst + 256);
+  const unsigned voff = 4u * (unsigned)lane;
+  if (lane < 2 * count) dma4_s(src, voff, lds_dst);
+  if (lane + 64 < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 256, voff, lds_dst + 256);
 }
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // single-wave workgroup
@@ -351,33 +371,36 @@ template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int 
 // ---- reusable components ----------------------------------------------------------------------------------------
 // J stream: J (m_r x N, row-major) goes HBM -> LDS ring -> MFMA operand registers exactly once per pass.  Lane (g, j) of
 // 4-row group s fetches J(4s+g, 32h+2j .. +1) and later reads the same 16 bytes back, so the ring needs no layout: it is a
-// per-lane FIFO that costs no VGPRs.  Running per-lane source pointers and compile-time ring slots keep the per-group VALU
-// work at the four J^T r FMAs plus two pointer bumps.
+// per-lane FIFO that costs no VGPRs.  The source addresses are scalar bases (bumped on the SALU) plus one constant per-lane
+// offset, and the ring slots are compile-time, so the per-group VALU work is the four J^T r FMAs and nothing else.
 template <int NT, int D>
 struct JStream {
   static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, DPS = NH + 1, SLOT = NH * 1024 + 64;
   static_assert(D >= 2 && D <= 8, "ring depth");
-  const char* jsrc;
-  const char* rsrc;
+  const char* jbase;   // wave-uniform: row 4s of J
+  const char* rbase;   // wave-uniform: r + 4s
+  unsigned joff, roff; // per-lane byte offsets inside a 4-row group / inside r[4s .. 4s+3]
   const char* lane_piece;
   const char* r_elem;
   unsigned ring_base;
   int lane, nsteps;
 
   __device__ inline void init(const double* Jp, const double* rg, const char* smem, unsigned ring_base_, int lane_, int g, int j, int m_r) {
-    jsrc = reinterpret_cast<const char*>(Jp + (size_t)g * N + 2 * j);
-    rsrc = reinterpret_cast<const char*>(rg + 2 * lane_);  // lanes 0,1 fetch r[4s .. 4s+3]
+    jbase = reinterpret_cast<const char*>(Jp);
+    rbase = reinterpret_cast<const char*>(rg);
+    joff = (unsigned)(g * N + 2 * j) * 8u;
+    roff = 16u * (unsigned)lane_;                            // lanes 0,1 fetch r[4s .. 4s+3]
     lane_piece = smem + lane_ * 16;                          // this lane's 16 bytes inside a 1 KiB DMA piece
     r_elem = smem + NH * 1024 + 8 * g;                       // r[4s + g] inside a slot
     ring_base = ring_base_; lane = lane_; nsteps = m_r >> 2;
   }
   template <int SL> __device__ inline void issue() {  // DMAs of the next not-yet-issued 4-row group into ring slot SL
     const unsigned dst = ring_base + SL * SLOT;
-#pragma unroll
-    for (int h = 0; h < NH; ++h) dma16(jsrc + 256 * h, dst + h * 1024);
-    if (lane < 2) dma16(rsrc, dst + NH * 1024);
-    jsrc += 4 * N * 8;
-    rsrc += 32;
+    dma16_s<0>(jbase, joff, dst);
+    if (NH > 1) dma16_s<256>(jbase, joff, dst + 1024 - 256);  // the instruction offset also advances the LDS address
+    if (lane < 2) dma16_s<0>(rbase, roff, dst + NH * 1024);
+    jbase += 4 * N * 8;
+    rbase += 32;
   }
   __device__ inline void wait_for_oldest(int younger) const {  // `younger` groups (DPS DMAs each) may stay in flight
     if (younger >= D - 1) { wait_vmcnt<(D - 1) * DPS>(); return; }
@@ -587,7 +610,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     dma_doubles(vp, vec_base, N, lane);                                                     // x -> xs
     if (m > 0) {
       const long long coff = p * ka->cons_stride;
-      if (lane < m) dma4(ka->cons_var + coff + lane, vec_base + (3 * N + 256) * 8);
+      if (lane < m) dma4_s(ka->cons_var + coff, 4u * (unsigned)lane, vec_base + (3 * N + 256) * 8);
       dma_doubles((const double*)ka->cons_a + coff, vec_base + (3 * N) * 8, m, lane);
       dma_doubles((const double*)ka->cons_b + coff, vec_base + (3 * N + 64) * 8, m, lane);
       dma_doubles(vp + N, vec_base + (3 * N + 128) * 8, m, lane);                            // s
