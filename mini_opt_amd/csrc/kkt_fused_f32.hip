@@ -481,8 +481,16 @@ const char* fused_f32_name(const KernelArgs& a) { return a.n == 128 ? "fused_mfm
 hipError_t launch_fused_f32(const KernelArgs& a, int num_cus, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  if (a.n == 128) {
+  static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
+  if (a.n == 128 && env_wps == 1) {
     constexpr int WPS = 1;
+    long long grid = num_cus;
+    const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+  } else if (a.n == 128) {
+    constexpr int WPS = 2;  // 255 VGPRs, no scratch: the 216 accumulator registers + operands just fit two waves per SIMD
     long long grid = num_cus;
     const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
     if (grid > need) grid = need;
