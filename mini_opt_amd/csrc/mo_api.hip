@@ -4,6 +4,7 @@
 // device every entry point fails with MO_ERR_NO_DEVICE / MO_ERR_HIP.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -95,7 +96,8 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
   a.ticket = plan->ticket;
   MO_HIP_CHECK(hipSetDevice(plan->desc.device));
   hipStream_t s = (hipStream_t)stream;
-  const bool force_generic = (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
+  static const bool env_force_generic = getenv("MO_FORCE_GENERIC") != nullptr;  // A/B and bisection knob
+  const bool force_generic = env_force_generic || (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
   if (!force_generic && mo::fused_supported(a, plan->desc.dtype)) {
     MO_HIP_CHECK(mo::launch_fused(a, plan->desc.dtype, plan->num_cus, s));
   } else if (!force_generic && mo::fused_f32_supported(a, plan->desc.dtype)) {
@@ -391,7 +393,7 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
   a.termination = termination; a.num_iterations = num_iterations; a.iterations = iterations; a.lagrange = lagrange;
   a.status = status;
   a.ticket = plan->ticket;
-  const bool use_fused = !(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype);
+  const bool use_fused = !getenv("MO_FORCE_GENERIC") && !(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype);
   if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch
     if (batch > plan->desc.max_batch) return fail(MO_ERR_INVALID_ARGUMENT, "batch %lld > plan max_batch %lld", (long long)batch, (long long)plan->desc.max_batch);
     const size_t n = (size_t)plan->desc.n;

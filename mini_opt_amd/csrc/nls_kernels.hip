@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void shift_constraints_kernel(const AuxArgs a)
     if (a.cons_a_out) ((T*)a.cons_a_out)[p * a.cons_b_out_stride + i] = ca;
   }
   T l1 = 0;
-  for (int i = lane; i < a.k; i += 64) l1 += fabs(((const T*)a.b)[p * a.b_stride + i]);                  // nonlinear.cc:203
-  l1 = wave_sum(l1);
+  if (a.out2 && a.b) {  // mo_nls_solve takes both error terms from nonlinear_errors_kernel and passes neither pointer
+    for (int i = lane; i < a.k; i += 64) l1 += fabs(((const T*)a.b)[p * a.b_stride + i]);                // nonlinear.cc:203
+    l1 = wave_sum(l1);
+  }
   const bool any_bad = __any(bad);
   if (lane == 0) {
     if (a.out2) ((T*)a.out2)[2 * p + 1] = l1;

@@ -264,3 +264,46 @@ def test_nls_with_device_residual_families():
     x = c.variables().cpu().numpy()
     dist = np.min(np.linalg.norm(x[:, None, :] - np.array(P.SPHERE_SOLUTIONS)[None], axis=2), axis=1)
     assert dist.max() < 5e-5
+
+
+def test_nls_on_the_fused_solve_kernel_with_per_problem_lambda():
+    """n = 32 with a row count the fused kernels accept: inside mo_nls_solve the QPs run on the fused Solve kernel with the
+    per-problem lambda vector (mo_problem.lambda_vec).  Sphere cost, four product equalities, a box on eight variables; parity with
+    the oracle's SQP loop, problem by problem."""
+    n, k = 32, 4
+    prods = np.array([4.0, 9.0, 1.0, 2.25])
+    cons = P.box(-6.0, 6.0, nvars=8)
+
+    def cost_np(x, want_J):
+        return np.array(x, float), (np.eye(n) if want_J else None)
+
+    def eq_np(x, want_J):
+        r = np.array([x[2 * q] * x[2 * q + 1] - prods[q] for q in range(k)])
+        J = None
+        if want_J:
+            J = np.zeros((k, n))
+            for q in range(k):
+                J[q, 2 * q], J[q, 2 * q + 1] = x[2 * q + 1], x[2 * q]
+        return r, J
+
+    kw = dict(max_iterations=60, max_qp_iterations=10, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-9,
+              termination_kkt_tolerance=1e-6, lambda_initial=0.001)
+    rng = np.random.default_rng(17)
+    guesses = rng.uniform(-5.0, 5.0, (48, n))
+    dprob = NLS.Problem(n, NLS.DeviceFamily(NLS.SPHERE, n), cost_rows=n, equality=NLS.DeviceFamily(NLS.PRODUCT_PAIRS, k, params=T(prods)),
+                        equality_rows=k, inequality_constraints=cons)
+    op, dp = params_pair(**kw)
+    out, x, term, nit, rx, rterm, rnit, logs = run_both(N.Problem(n, cost_np, equality=eq_np, inequality_constraints=cons), dprob, op, dp, guesses)
+    sat = NLS.TerminationStateIndicatesSatisfiedTol(torch.as_tensor(term)).numpy()
+    assert sat.mean() > 0.5 and np.array_equal(sat, np.isin(rterm, [1, 2, 3]))        # some starts run out of iterations, as in the oracle
+    # at an optimum the pairs satisfy x_{2q} x_{2q+1} = v_q with |x_{2q}| = |x_{2q+1}| and everything else is 0
+    for q in range(k):
+        np.testing.assert_allclose(x[sat, 2 * q] * x[sat, 2 * q + 1], prods[q], atol=1e-6)
+        np.testing.assert_allclose(np.abs(x[sat, 2 * q]), np.sqrt(prods[q]), atol=5e-4)
+    np.testing.assert_allclose(x[sat][:, 2 * k:], 0.0, atol=5e-5)
+    same = (term == rterm) & (nit == rnit)
+    assert same.mean() > 0.9, same.mean()
+    np.testing.assert_allclose(x[same], rx[same], atol=1e-6)
+    # lambda really differs from problem to problem along the way (the per-problem vector is exercised)
+    lam = out.iterations.cpu().numpy()[:, :, 1]
+    assert np.nanmax(np.nanstd(lam, axis=0)) > 0 or np.all(nit == nit[0])
