@@ -307,3 +307,44 @@ def test_nls_on_the_fused_solve_kernel_with_per_problem_lambda():
     # lambda really differs from problem to problem along the way (the per-problem vector is exercised)
     lam = out.iterations.cpu().numpy()[:, :, 1]
     assert np.nanmax(np.nanstd(lam, axis=0)) > 0 or np.all(nit == nit[0])
+
+
+def test_fp32_variants_of_the_support_entry_points():
+    """mo_fill_qp / mo_qp_cost_derivative / mo_residual_eval / mo_nullspace_solve on fp32 plans (mo_nls_solve itself is fp64-only
+    and says so)."""
+    rng = np.random.default_rng(23)
+    dt = torch.float32
+    f = lambda a_: a_.astype(np.float32).astype(np.float64)
+    B, n, k, m, m_r = 21, 10, 2, 5, 16
+    J = f(rng.uniform(-1, 1, (B, m_r, n))); r = f(rng.uniform(-1, 1, (B, m_r)))
+    A = f(rng.uniform(-1, 1, (B, k, n))); b = f(rng.uniform(-1, 1, (B, k)))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0], (B, m)); cb = f(rng.uniform(-1, 1, (B, m)))
+    x = f(rng.uniform(-2, 2, (B, n))); dx = f(rng.uniform(-1, 1, (B, n)))
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J, dt), r=T(r, dt), lam=0.25, A_eq=T(A.transpose(0, 2, 1), dt), b_eq=T(b, dt),
+                       cons_var=T(cv, torch.int32), cons_a=T(ca, dt), cons_b=T(cb, dt))
+    G, c, cbs, err, status = NLS.fill_qp(prob, T(x, dt))
+    assert torch.all(status == 0)
+    Gref = np.einsum("bqi,bqj->bij", J, J) + 0.25 * np.eye(n)
+    np.testing.assert_allclose(np.tril(G.double().cpu().numpy().transpose(0, 2, 1)), np.tril(Gref), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cbs.double().cpu().numpy(), ca * np.take_along_axis(x, cv, 1) + cb, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(err.double().cpu().numpy(), np.stack([0.5 * np.sum(r * r, 1), np.sum(np.abs(b), 1)], 1), rtol=1e-5)
+    d1, q1 = NLS.qp_cost_derivative(prob, T(dx, dt))
+    dref = np.stack([np.einsum("bi,bi->b", np.einsum("bqi,bq->bi", J, r), dx),
+                     np.einsum("bk,bk->b", np.sign(b), np.einsum("bkn,bn->bk", A, dx))], 1)
+    np.testing.assert_allclose(d1.double().cpu().numpy(), dref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(q1.double().cpu().numpy(), np.einsum("bi,bij,bj->b", dx, Gref, dx), rtol=1e-4)
+    rr, JJ = NLS.DeviceFamily(NLS.ROSENBROCK, 10)(T(x[:, :6], dt), True)
+    r0, J0 = P.rosenbrock6_torch(T(x[:, :6], dt), True)
+    np.testing.assert_allclose(rr.cpu().numpy(), r0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(JJ.cpu().numpy(), J0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    s = Q.QPNullSpaceSolver()
+    term = s.Solve(Q.BatchedQP(n=n, k=k, J=T(J, dt), r=T(r, dt), lam=0.25, A_eq=T(A.transpose(0, 2, 1), dt), b_eq=T(b, dt)))
+    assert torch.all(term == 0)
+    xs = s.variables().double().cpu().numpy()
+    for p in range(B):
+        ok, xr = N.null_space_solve(N.QPData(np.tril(Gref[p]), np.einsum("qi,q->i", J[p], r[p]), A[p], b[p], []))
+        assert ok
+        np.testing.assert_allclose(xs[p], xr, rtol=2e-3, atol=2e-4)
+    from mini_opt_amd import _lib as L
+    with pytest.raises(L.MiniOptError):
+        NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, P.rosenbrock_torch, cost_rows=2), batch=2, dtype=torch.float32)
