@@ -162,24 +162,61 @@ template <int NT, bool QPL> __device__ inline void stv(double* arr, int j, const
     for (int h = 0; h < NT / 2; ++h) { d2 t; t[0] = v[2 * h]; t[1] = v[2 * h + 1]; *(d2*)(arr + 32 * h + 2 * j) = t; }
   }
 }
+// The same on the caller's arrays of length nn <= 16 NT (the kernels pad the system to whole tiles: padded variables have zero
+// cost / constraint columns, a unit diagonal and therefore a zero solution).  J-level input has nn even, so a pair is in or out.
+template <int NT, bool QPL> __device__ inline void ldv_n(const double* arr, int j, int nn, double (&v)[NT]) {
+  if (QPL) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) v[c] = (16 * c + j < nn) ? arr[16 * c + j] : 0.0;
+  } else {
+#pragma unroll
+    for (int h = 0; h < NT / 2; ++h) {
+      d2 t = d2{0.0, 0.0};
+      if (32 * h + 2 * j < nn) t = *(const d2*)(arr + 32 * h + 2 * j);
+      v[2 * h] = t[0]; v[2 * h + 1] = t[1];
+    }
+  }
+}
+template <int NT, bool QPL> __device__ inline void stv_n(double* arr, int j, int nn, const double (&v)[NT]) {
+  if (QPL) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+      if (16 * c + j < nn) arr[16 * c + j] = v[c];
+  } else {
+#pragma unroll
+    for (int h = 0; h < NT / 2; ++h) {
+      d2 t; t[0] = v[2 * h]; t[1] = v[2 * h + 1];
+      if (32 * h + 2 * j < nn) *(d2*)(arr + 32 * h + 2 * j) = t;
+    }
+  }
+}
+// 1.0 where the variable at tile position 16c + j is padding (index >= nn), else 0.0
+template <int NT, bool QPL> __device__ inline void pad_diag(int j, int nn, double (&v)[NT]) {
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    const int nat = QPL ? 16 * c + j : 32 * (c >> 1) + 2 * j + (c & 1);
+    v[c] = nat >= nn ? 1.0 : 0.0;
+  }
+}
 // [A_eq^T | .] tile column: element (row r = g + 4t of block c, column j < k) = A_eq(j, variable of position 16c + r).
 template <int NT, bool QPL>
-__device__ inline void load_a_tiles(const double* Ap, int A_ld, int k, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)]) {
+__device__ inline void load_a_tiles(const double* Ap, int A_ld, int k, int nn, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)]) {
   constexpr int NB = NT + 1;
-  const double* Al = Ap + j + (size_t)((QPL ? 1 : 2) * g) * A_ld;  // per-lane part of the column offset
+  const int col_l = (QPL ? 1 : 2) * g;                             // per-lane part of the column index
+  const double* Al = Ap + j + (size_t)col_l * A_ld;
 #pragma unroll
   for (int c = 0; c < NT; ++c) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int col_u = QPL ? (16 * c + 4 * t) : (32 * (c >> 1) + 8 * t + (c & 1));  // wave-uniform part
-      U[c * NB + NT][t] = (j < k) ? Al[(size_t)col_u * A_ld] : 0.0;
+      U[c * NB + NT][t] = (j < k && col_u + col_l < nn) ? Al[(size_t)col_u * A_ld] : 0.0;
     }
   }
 }
 // QP-level cost: the G tiles come straight from the caller's column-major G (only its lower triangle is read, qp.cc:289):
 // tile (a, b), element (r, j) = G(16b + j, 16a + r) for b > a (128-byte rows across the lanes), mirrored inside diagonal tiles.
 template <int NT>
-__device__ inline void load_g_tiles(const double* G, int ld, const double* cg, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)],
+__device__ inline void load_g_tiles(const double* G, int ld, const double* cg, int nn, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)],
                                     double (&cvec)[NT]) {
   constexpr int NB = NT + 1;
 #pragma unroll
@@ -191,10 +228,10 @@ __device__ inline void load_g_tiles(const double* G, int ld, const double* cg, i
         const int r = g + 4 * t;
         int row = 16 * tb + j, col = 16 * ta + r;
         if (ta == tb && r > j) { row = 16 * ta + r; col = 16 * ta + j; }
-        U[ta * NB + tb][t] = G[row + (size_t)col * ld];
+        U[ta * NB + tb][t] = (row < nn && col < nn) ? G[row + (size_t)col * ld] : 0.0;
       }
     }
-    cvec[ta] = cg[16 * ta + j];
+    cvec[ta] = (16 * ta + j < nn) ? cg[16 * ta + j] : 0.0;
   }
 }
 
@@ -380,15 +417,20 @@ struct JStream {
   const char* jbase;   // wave-uniform: row 4s of J
   const char* rbase;   // wave-uniform: r + 4s
   unsigned joff, roff; // per-lane byte offsets inside a 4-row group / inside r[4s .. 4s+3]
+  unsigned jstep;      // bytes per 4-row group (4 nn doubles)
+  bool act0, act1;     // does this lane's piece h lie inside the row (nn < N pads the system; the ring is zeroed once)
   const char* lane_piece;
   const char* r_elem;
   unsigned ring_base;
   int lane, nsteps;
 
-  __device__ inline void init(const double* Jp, const double* rg, const char* smem, unsigned ring_base_, int lane_, int g, int j, int m_r) {
+  __device__ inline void init(const double* Jp, const double* rg, const char* smem, unsigned ring_base_, int lane_, int g, int j, int m_r,
+                              int nn = N) {
     jbase = reinterpret_cast<const char*>(Jp);
     rbase = reinterpret_cast<const char*>(rg);
-    joff = (unsigned)(g * N + 2 * j) * 8u;
+    joff = (unsigned)(g * nn + 2 * j) * 8u;
+    jstep = 32u * (unsigned)nn;
+    act0 = 2 * j < nn; act1 = 32 + 2 * j < nn;
     roff = 16u * (unsigned)lane_;                            // lanes 0,1 fetch r[4s .. 4s+3]
     lane_piece = smem + lane_ * 16;                          // this lane's 16 bytes inside a 1 KiB DMA piece
     r_elem = smem + NH * 1024 + 8 * g;                       // r[4s + g] inside a slot
@@ -396,10 +438,10 @@ struct JStream {
   }
   template <int SL> __device__ inline void issue() {  // DMAs of the next not-yet-issued 4-row group into ring slot SL
     const unsigned dst = ring_base + SL * SLOT;
-    dma16_s<0>(jbase, joff, dst);
-    if (NH > 1) dma16_s<256>(jbase, joff, dst + 1024 - 256);  // the instruction offset also advances the LDS address
+    if (act0) dma16_s<0>(jbase, joff, dst);                            // at least lane 0 of every piece is inside the row
+    if (NH > 1 && act1) dma16_s<256>(jbase, joff, dst + 1024 - 256);  // the instruction offset also advances the LDS address
     if (lane < 2) dma16_s<0>(rbase, roff, dst + NH * 1024);
-    jbase += 4 * N * 8;
+    jbase += jstep;
     rbase += 32;
   }
   __device__ inline void wait_for_oldest(int younger) const {  // `younger` groups (DPS DMAs each) may stay in flight
@@ -545,6 +587,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   const unsigned vec_base = ring_base + D * SLOT;                 // LDS byte address of xs
 
   const int k = a.k, m = a.m, m_r = a.m_r;
+  const int nn = a.n;  // actual number of variables <= N; the system is padded to whole tiles (unit diagonal, zero solution)
+  // Once per wave: the ring (lanes whose J piece lies beyond the row never receive DMA data and must read zeros) and x's padding.
+  for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
+  for (int i = (int)(threadIdx.x & 63); i < N; i += 64) xs[i] = 0.0;
+  lds_fence();
 #ifdef MO_FUSED_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -598,7 +645,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
     JStream<NT, D> stream;
     if (!QPL) {
-      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
+      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
       stream.prologue();
     }
 
@@ -607,21 +654,21 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     d4 U[NB * NB];
 #pragma unroll
     for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-    dma_doubles(vp, vec_base, N, lane);                                                     // x -> xs
+    dma_doubles(vp, vec_base, nn, lane);                                                    // x -> xs
     if (m > 0) {
       const long long coff = p * ka->cons_stride;
       if (lane < m) dma4_s(ka->cons_var + coff, 4u * (unsigned)lane, vec_base + (3 * N + 256) * 8);
       dma_doubles((const double*)ka->cons_a + coff, vec_base + (3 * N) * 8, m, lane);
       dma_doubles((const double*)ka->cons_b + coff, vec_base + (3 * N + 64) * 8, m, lane);
-      dma_doubles(vp + N, vec_base + (3 * N + 128) * 8, m, lane);                            // s
-      dma_doubles(vp + N + m + k, vec_base + (3 * N + 192) * 8, m, lane);                    // z
+      dma_doubles(vp + nn, vec_base + (3 * N + 128) * 8, m, lane);                           // s
+      dma_doubles(vp + nn + m + k, vec_base + (3 * N + 192) * 8, m, lane);                   // z
     }
     if (k > 0) {
-      dma_doubles(vp + N + m, vec_base + (3 * N + 288) * 8, k, lane);                        // y
+      dma_doubles(vp + nn + m, vec_base + (3 * N + 288) * 8, k, lane);                       // y
       dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 304) * 8, k, lane);  // b_eq
     }
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
-    load_a_tiles<NT, QPL>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, g, j, U);
+    load_a_tiles<NT, QPL>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, nn, g, j, U);
 
     MO_STAMP(0);
     // ---- P1: stream J once through the LDS-DMA ring; G = J^T J on the matrix cores (upper block triangle of tiles),
@@ -632,7 +679,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
     double cvec[NT];  // c (= J^T r) at position 16c + j (replicated over g)
     if (QPL) {
-      load_g_tiles<NT>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, g, j, U, cvec);
+      load_g_tiles<NT>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, nn, g, j, U, cvec);
     } else {
       stream.run(U, cpart);
 #pragma unroll
@@ -651,7 +698,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     int cvar = 0; double ca = 1.0, cb = 0.0, cs = 1.0, cz = 0.0;
     if (lane < m) { cvar = cV[lane]; ca = cA[lane]; cb = cB[lane]; cs = cS[lane]; cz = cZ[lane]; }
     lds_fence();  // diagS / rhsS initialised
-    bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= N));
+    bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= nn));
     if (bad_index) cvar = 0;
     const bool slack_bad = __any((lane < m) && !(cs > 0.0));
     const bool any_bad_index = __any(bad_index);
@@ -681,11 +728,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     }
     const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
     const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
+    double padv[NT];
+    pad_diag<NT, QPL>(j, nn, padv);
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        U[c * NB + c][t] += (j == g + 4 * t) ? (lam + dS[c]) : 0.0;
+        U[c * NB + c][t] += (j == g + 4 * t) ? (lam + dS[c] + padv[c]) : 0.0;
         const double rv = rp[16 * c + g + 4 * t];
         if (j == kRC) U[c * NB + NT][t] = rv;
       }
@@ -757,12 +806,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       double outv[NT];
 #pragma unroll
       for (int c = 0; c < NT; ++c) outv[c] = st == MO_STATUS_OK ? dxv[c] : nanv;
-      stv<NT, QPL>(dp, j, outv);
-      if (j < k) dp[N + m + j] = st == MO_STATUS_OK ? dyv : nanv;
+      stv_n<NT, QPL>(dp, j, nn, outv);
+      if (j < k) dp[nn + m + j] = st == MO_STATUS_OK ? dyv : nanv;
     }
     if (lane < m) {
-      dp[N + lane] = st == MO_STATUS_OK ? dsv : nanv;
-      dp[N + m + k + lane] = st == MO_STATUS_OK ? dzv : nanv;
+      dp[nn + lane] = st == MO_STATUS_OK ? dsv : nanv;
+      dp[nn + m + k + lane] = st == MO_STATUS_OK ? dzv : nanv;
     }
     if (lane == 0) {
       if (ka->alpha) {
@@ -832,7 +881,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
   const int k = a.k, m = a.m, m_r = a.m_r;
+  const int nn = a.n;  // actual number of variables <= N (see the step kernel)
   const mo_solve_params& sp = a.sp;
+  for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
+  lds_fence();
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);  // ~ remaining / (4 waves' worth)
   auto chunk_for = [&](long long observed) -> int {
@@ -886,11 +938,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     for (int c = 0; c < NT; ++c) xv[c] = 0.0;
     const bool iterate_mode = a.mode == MODE_ITERATE;  // one Iterate (qp.cc:153-201) on the caller's state and mu
     if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
-      ldv<NT, QPL>(vp, j, xv);
-      if (j < k) yv = vp[N + m + j];
-      if (lane < m) { cs = vp[N + lane]; cz = vp[N + m + k + lane]; }
+      ldv_n<NT, QPL>(vp, j, nn, xv);
+      if (j < k) yv = vp[nn + m + j];
+      if (lane < m) { cs = vp[nn + lane]; cz = vp[nn + m + k + lane]; }
     }
-    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= N)));
+    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= nn)));
     if (bad_index) cvar = 0;
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
@@ -953,13 +1005,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       JStream<NT, D> stream;
       if (!QPL) {
-        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r);
+        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
         stream.prologue();
       }
       d4 U[NB * NB];
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-      load_a_tiles<NT, QPL>(Ap, a.A_ld, k, g, j, U);
+      load_a_tiles<NT, QPL>(Ap, a.A_ld, k, nn, g, j, U);
       // publish the state for the layout conversions below; zero the per-variable scatter arrays
       if (g == 0) {
         stv<NT, QPL>(xs, j, xv);
@@ -974,7 +1026,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       double cvec[NT];
       if (QPL) {
-        load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, g, j, U, cvec);
+        load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, nn, g, j, U, cvec);
       } else {
         double cpart[NT];
 #pragma unroll
@@ -987,6 +1039,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+      }
+      {  // unit diagonal for the padding variables (index >= nn): they stay at zero
+        double padv[NT];
+        pad_diag<NT, QPL>(j, nn, padv);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? padv[c] : 0.0;
+        }
       }
       lds_fence();
       double r_pi = 0.0, r_comp = 0.0;
@@ -1181,9 +1242,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
         if (a.delta) {
           double* dp = (double*)a.delta + p * a.delta_stride;
-          if (lane < N) dp[lane] = tmp[lane];  // dx, natural order
-          if (lane < m) { dp[N + lane] = dsv; dp[N + m + k + lane] = dzv; }
-          if (g == 0 && j < k) dp[N + m + j] = dyv;
+          if (lane < nn) dp[lane] = tmp[lane];  // dx, natural order
+          if (lane < m) { dp[nn + lane] = dsv; dp[nn + m + k + lane] = dzv; }
+          if (g == 0 && j < k) dp[nn + m + j] = dyv;
         }
         if (a.ip_out && lane == 0) {
           double* ip = (double*)a.ip_out + p * MO_IP_RECORD;
@@ -1196,10 +1257,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
     // ---- outputs: state, termination, iteration count, Lagrange summary, status
     if (g == 0) {
-      stv<NT, QPL>(vp, j, xv);
-      if (j < k) vp[N + m + j] = yv;
+      stv_n<NT, QPL>(vp, j, nn, xv);
+      if (j < k) vp[nn + m + j] = yv;
     }
-    if (lane < m) { vp[N + lane] = cs; vp[N + m + k + lane] = cz; }
+    if (lane < m) { vp[nn + lane] = cs; vp[nn + m + k + lane] = cz; }
     const double ymin = row_min((j < k) ? yv : INFINITY), yabs = -row_min((j < k) ? -fabs(yv) : INFINITY);
     if (lane == 0) {
       if (a.termination) a.termination[p] = term;
@@ -1227,12 +1288,13 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64 || a.flags != 0) return false;
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
-  if (a.n != 32 && a.n != 64) return false;
+  if (a.n < 2 || a.n > 64) return false;  // padded to 32 or 64 variables inside the kernel
   if (a.k > 14 || a.m > 64 || a.m < 0) return false;
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of J, r and of the state / direction vectors
     if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
+    if (a.n & 1) return false;  // rows of J must start on 16-byte boundaries
     if (!aligned16(a.J) || (a.J_stride & 1)) return false;
     if (!aligned16(a.r) || (a.r_stride & 1)) return false;
     if (!aligned16(a.vars) || (a.vars_stride & 1)) return false;
@@ -1245,18 +1307,18 @@ bool fused_supported(const KernelArgs& a, int dtype) {
 
 const char* fused_name(const KernelArgs& a, int) {
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {
-    if (!a.J) return a.n == 64 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
-    return a.n == 64 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
+    if (!a.J) return a.n > 32 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
+    return a.n > 32 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
   }
-  if (!a.J) return a.n == 64 ? "fused_qp_f64_n64" : "fused_qp_f64_n32";
-  return a.n == 64 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
+  if (!a.J) return a.n > 32 ? "fused_qp_f64_n64" : "fused_qp_f64_n32";  // the tile grid the problem is padded to
+  return a.n > 32 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
 }
 
 hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t stream) {
   // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
   static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
-  const int wps = a.n == 64 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);  // measured best: 3 (A/B in DESIGN.md)
+  const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);  // measured best: 3 (A/B in DESIGN.md)
   const int sw = (env_sw >= 0 && env_sw <= 3) ? env_sw : 3;
   long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
   const long long blocks_needed = (a.batch + 4 * wps - 1) / (4 * wps);
@@ -1265,13 +1327,13 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
-    const int swps = a.n == 64 ? 2 : 3;
+    const int swps = a.n > 32 ? 2 : 3;
     long long sgrid = num_cus;
     const long long need = (a.batch + 4 * swps - 1) / (4 * swps);
     if (sgrid > need) sgrid = need;
     if (sgrid < 1) sgrid = 1;
     const dim3 sgd((unsigned)sgrid), sbd(256 * swps);
-    if (a.n == 64) {
+    if (a.n > 32) {
       if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false>), sgd, sbd, 0, stream, a);
       else hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, true>), sgd, sbd, 0, stream, a);
     } else {
@@ -1282,7 +1344,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   }
   const dim3 gd((unsigned)grid), bd(256 * wps);
   if (!a.J) {  // QP-level input: default flavour only
-    if (a.n == 64) {
+    if (a.n > 32) {
       if (wps == 3) hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, true>), gd, bd, 0, stream, a);
       else hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 2, 3, true>), gd, bd, 0, stream, a);
     } else {
@@ -1299,7 +1361,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     else if (sw == 2) MO_FUSED_LAUNCH(NT_, WPS_, 2);  \
     else MO_FUSED_LAUNCH(NT_, WPS_, 3);               \
   } while (0)
-  if (a.n == 64) {
+  if (a.n > 32) {
     if (wps == 3) MO_FUSED_BY_SW(4, 3); else MO_FUSED_BY_SW(4, 2);
   } else {
     if (wps == 3) MO_FUSED_BY_SW(2, 3); else MO_FUSED_BY_SW(2, 4);

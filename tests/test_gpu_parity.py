@@ -561,3 +561,54 @@ def test_fused_f32_status_words():
     assert st[5] in (L.MO_STATUS_NONFINITE, L.MO_STATUS_FACTORIZATION_FAILED)
     dn = delta.cpu().numpy()
     assert np.all(np.isnan(dn[[1, 4, 5, 6]])) and np.all(np.isfinite(dn[good]))
+
+
+# ------------------------------------------------------------------ fused fp64 kernels on sizes that are padded to the tile grid
+@pytest.mark.parametrize("n,k,m,m_r,level", [(20, 2, 6, 24, "J"), (34, 4, 10, 40, "J"), (46, 0, 8, 48, "J"), (62, 14, 2, 64, "J"),
+                                             (2, 0, 4, 0, "QP"), (7, 2, 3, 0, "QP"), (33, 5, 12, 0, "QP"), (50, 8, 0, 0, "QP")])
+def test_fused_padded_sizes(n, k, m, m_r, level):
+    """Any n <= 64 runs on the fused kernels (even n for J-level input): the system is padded to 32 / 64 variables with a unit
+    diagonal inside the kernel.  Newton step and the whole Solve against the oracle."""
+    rng = np.random.default_rng(n * 131 + k * 17 + m)
+    B = 23
+    mr = m_r if m_r else 2 * n
+    J = rng.uniform(-1, 1, (B, mr, n)); r = rng.uniform(-1, 1, (B, mr))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32)
+    ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n))
+    sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    if level == "J" and vars_.shape[1] % 2:
+        pytest.skip("odd V with J-level input: 16-byte alignment of the state")
+    mu = np.full(B, 0.05)
+    lam = 1e-3
+    G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    c = np.einsum("bqi,bq->bi", J, r)
+    common = dict(A_eq=T(A) if k else None, b_eq=T(b) if k else None, cons_var=T(cv, torch.int32) if m else None,
+                  cons_a=T(ca) if m else None, cons_b=T(cb) if m else None)
+    if level == "J":
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common)
+    else:
+        prob = Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), **common)
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused"), s.step_kernel()
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
+        n, k, m, G=np.tril(G).transpose(0, 2, 1).copy(), c=c, A_eq=A if k else None, b_eq=b if k else None, cons_var=cv if m else None,
+        cons_a=ca if m else None, cons_b=cb if m else None, vars_=vars_, mu=mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-9
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+    # the whole Solve, fused vs generic (the generic kernel is pinned against the oracle elsewhere)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-9, max_iterations=12, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+    res = {}
+    for force in (False, True):
+        sv = Q.QPInteriorPointSolver(prob, force_generic=force)
+        out = sv.Solve(Q.Params(**kw))
+        assert torch.all(out.status == 0)
+        res[force] = (sv.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
+    same = (res[False][1] == res[True][1]) & (res[False][2] == res[True][2])
+    assert same.mean() >= 0.9
+    np.testing.assert_allclose(res[False][0][same], res[True][0][same], rtol=1e-6, atol=1e-8)
