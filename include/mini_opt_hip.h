@@ -24,7 +24,8 @@
  *    (qp.cc:36-42, 548-582); V = n + 2m + k.
  *  - dtype MO_F64 is the reference's arithmetic (qp.hpp:15: double only); MO_F32 is the BASELINE.json cfg-4
  *    extension: every floating-point tensor (incl. mu, alpha, ip records) is then float.
- *  - Thread-safety: a plan may be used from one host thread at a time; distinct plans are independent.
+ *  - Thread-safety: a plan may be used from one host thread -- and one stream -- at a time (it owns the device work counter
+ *    of the fused kernels and the scratch of mo_qp_solve); distinct plans are independent.
  *    Multi-GPU = one plan (and one process or thread) per device; there is no cross-device traffic.
  */
 #ifndef MINI_OPT_HIP_H_
