@@ -612,3 +612,69 @@ def test_fused_padded_sizes(n, k, m, m_r, level):
     same = (res[False][1] == res[True][1]) & (res[False][2] == res[True][2])
     assert same.mean() >= 0.9
     np.testing.assert_allclose(res[False][0][same], res[True][0][same], rtol=1e-6, atol=1e-8)
+
+
+# ------------------------------------------------------------------ randomised shape sweep: fused vs generic kernel (the generic one is pinned above)
+def test_fused_vs_generic_random_shapes():
+    """Forty random (n, k, m, m_r, input level, strategy) combinations through the fused kernels and through the generic kernel
+    (MO_PLAN_FORCE_GENERIC): Newton step, Iterate (incl. predictor-corrector) and Solve must agree."""
+    rng = np.random.default_rng(2026)
+    tried = 0
+    while tried < 40:
+        level = rng.choice(["J", "QP"])
+        n = int(rng.integers(1, 33)) * 2 if level == "J" else int(rng.integers(2, 65))
+        k = int(rng.integers(0, min(15, n)))
+        m = int(rng.integers(0, 65))
+        m_r = int(rng.integers(1, 40)) * 4
+        V = n + 2 * m + k
+        if level == "J" and V % 2:
+            continue
+        tried += 1
+        B = 9
+        J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+        A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+        cv = rng.integers(0, n, (B, m)).astype(np.int32)
+        ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+        x = rng.uniform(-0.1, 0.1, (B, n))
+        sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+        vars_ = np.concatenate([x, sl, y, z], axis=1)
+        mu = np.full(B, 0.05)
+        lam = 0.3 if m_r < n else 1e-3
+        common = dict(A_eq=T(A) if k else None, b_eq=T(b) if k else None, cons_var=T(cv, torch.int32) if m else None,
+                      cons_a=T(ca) if m else None, cons_b=T(cb) if m else None)
+        if level == "J":
+            prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common)
+        else:
+            G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+            prob = Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(np.einsum("bqi,bq->bi", J, r)), **common)
+        tag = (level, n, k, m, m_r)
+        strategy = int(rng.integers(0, 3))
+        got = {}
+        for force in (False, True):
+            s = Q.QPInteriorPointSolver(prob, force_generic=force)
+            if not force:
+                assert s.step_kernel().startswith("fused"), (tag, s.step_kernel())
+            s.SetVariables(T(vars_))
+            delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+            assert torch.all(status == 0), tag
+            ip, st2 = s.Iterate(T(mu), strategy)
+            assert torch.all(st2 == 0), tag
+            after_iter = s.variables().cpu().numpy().copy()
+            out = s.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=10, barrier_strategy=strategy,
+                                   initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
+            assert torch.all(out.status == 0), tag
+            got[force] = (delta.cpu().numpy(), alpha.cpu().numpy(), ip.cpu().numpy(), after_iter, s.variables().cpu().numpy().copy(),
+                          out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
+        f, g_ = got[False], got[True]
+        assert rel_inf_rows(f[0], g_[0]).max() < 1e-8, tag
+        np.testing.assert_allclose(f[1], g_[1], atol=1e-8, err_msg=str(tag))
+        np.testing.assert_allclose(f[2], g_[2], rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=str(tag))
+        np.testing.assert_allclose(f[3], g_[3], rtol=1e-7, atol=1e-9, err_msg=str(tag))
+        same = (f[5] == g_[5]) & (f[6] == g_[6])
+        assert same.mean() >= 0.75, (tag, f[5], g_[5])
+        # optimum: x of the problems that converged (random constraint sets can be nearly degenerate: multipliers reach 1e12, the
+        # interior-point loop runs into MAX_ITERATIONS and the two summation orders drift apart there)
+        conv = same & (f[6] == Q.SATISFIED_KKT_TOL)
+        if conv.any():
+            xa, xb_ = f[4][conv][:, :n], g_[4][conv][:, :n]
+            assert np.max(np.abs(xa - xb_)) <= 1e-5 * max(1.0, np.max(np.abs(xb_))), tag
