@@ -290,12 +290,16 @@ __device__ inline void dma4(const void* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
-// `count` consecutive doubles (count <= 64, wave-uniform) from global memory to LDS without touching a VGPR destination.
+// `count` consecutive doubles (count <= 128, wave-uniform) from global memory to LDS without touching a VGPR destination.
 // `src` must be wave-uniform.
 __device__ inline void dma_doubles(const double* src, unsigned lds_dst, int count, int lane) {
   const unsigned voff = 4u * (unsigned)lane;
   if (lane < 2 * count) dma4_s(src, voff, lds_dst);
   if (lane + 64 < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 256, voff, lds_dst + 256);
+  if (count > 64) {  // wave-uniform; up to 128 doubles (n = 96 / 128)
+    if (lane + 128 < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 512, voff, lds_dst + 512);
+    if (lane + 192 < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 768, voff, lds_dst + 768);
+  }
 }
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ inline void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // single-wave workgroup
@@ -418,7 +422,7 @@ struct JStream {
   const char* rbase;   // wave-uniform: r + 4s
   unsigned joff, roff; // per-lane byte offsets inside a 4-row group / inside r[4s .. 4s+3]
   unsigned jstep;      // bytes per 4-row group (4 nn doubles)
-  bool act0, act1;     // does this lane's piece h lie inside the row (nn < N pads the system; the ring is zeroed once)
+  bool act0, act1, act2, act3;  // does this lane's piece h lie inside the row (nn < N pads the system; the ring is zeroed once)
   const char* lane_piece;
   const char* r_elem;
   unsigned ring_base;
@@ -430,7 +434,7 @@ struct JStream {
     rbase = reinterpret_cast<const char*>(rg);
     joff = (unsigned)(g * nn + 2 * j) * 8u;
     jstep = 32u * (unsigned)nn;
-    act0 = 2 * j < nn; act1 = 32 + 2 * j < nn;
+    act0 = 2 * j < nn; act1 = 32 + 2 * j < nn; act2 = 64 + 2 * j < nn; act3 = 96 + 2 * j < nn;
     roff = 16u * (unsigned)lane_;                            // lanes 0,1 fetch r[4s .. 4s+3]
     lane_piece = smem + lane_ * 16;                          // this lane's 16 bytes inside a 1 KiB DMA piece
     r_elem = smem + NH * 1024 + 8 * g;                       // r[4s + g] inside a slot
@@ -440,6 +444,8 @@ struct JStream {
     const unsigned dst = ring_base + SL * SLOT;
     if (act0) dma16_s<0>(jbase, joff, dst);                            // at least lane 0 of every piece is inside the row
     if (NH > 1 && act1) dma16_s<256>(jbase, joff, dst + 1024 - 256);  // the instruction offset also advances the LDS address
+    if (NH > 2 && act2) dma16_s<512>(jbase, joff, dst + 2048 - 512);
+    if (NH > 3 && act3) dma16_s<768>(jbase, joff, dst + 3072 - 768);
     if (lane < 2) dma16_s<0>(rbase, roff, dst + NH * 1024);
     jbase += jstep;
     rbase += 32;
@@ -554,7 +560,7 @@ template <int NT, int WPS> struct FusedCfg {
   static constexpr int NH = NT / 2;                 // 16-byte J loads per lane per 4-row group
   static constexpr int DPS = NH + 1;                // LDS-DMA instructions per 4-row group (J pieces + 32 B of r)
   static constexpr int SLOT = NH * 1024 + 64;       // ring slot: 4 rows of J (lane-linear) + r[4s..4s+3]
-  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 7) : (WPS >= 4 ? 4 : 8);  // ring depth (4-row groups in flight per wave), LDS-limited
+  static constexpr int D = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 7) : (WPS >= 4 ? 4 : 8));  // ring depth (4-row groups in flight per wave), LDS-limited
   static constexpr int VEC = (3 * N + 4 * 64 + 32 + 32) * 8;  // xs, diagS|rp, rhsS|dxs, cons a/b/s/z [64], cons var [64 int], y[16], b_eq[16]
   static constexpr int LDS = D * SLOT + VEC;
 };
@@ -854,7 +860,7 @@ template <int NT, int WPS> struct SolveCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;
   static constexpr int SLOT = NH * 1024 + 64;
-  static constexpr int D = NT >= 4 ? (WPS >= 3 ? 4 : 6) : 8;
+  static constexpr int D = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
   static constexpr int VEC = (6 * N + 32 + 128) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32], affine ds / dz [2][64]
   static constexpr int LDS = D * SLOT + VEC;
 };
@@ -1242,7 +1248,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
         if (a.delta) {
           double* dp = (double*)a.delta + p * a.delta_stride;
-          if (lane < nn) dp[lane] = tmp[lane];  // dx, natural order
+          for (int i = lane; i < nn; i += 64) dp[i] = tmp[i];  // dx, natural order
           if (lane < m) { dp[nn + lane] = dsv; dp[nn + m + k + lane] = dzv; }
           if (g == 0 && j < k) dp[nn + m + j] = dyv;
         }
@@ -1288,7 +1294,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64 || a.flags != 0) return false;
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
-  if (a.n < 2 || a.n > 64) return false;  // padded to 32 or 64 variables inside the kernel
+  if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.k > 14 || a.m > 64 || a.m < 0) return false;
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
@@ -1307,11 +1313,12 @@ bool fused_supported(const KernelArgs& a, int dtype) {
 
 const char* fused_name(const KernelArgs& a, int) {
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {
-    if (!a.J) return a.n > 32 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
-    return a.n > 32 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
+    if (!a.J) return a.n > 96 ? "fused_solve_qp_f64_n128" : a.n > 64 ? "fused_solve_qp_f64_n96" : a.n > 32 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
+    return a.n > 96 ? "fused_solve_mfma_f64_n128" : a.n > 64 ? "fused_solve_mfma_f64_n96" : a.n > 32 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
   }
-  if (!a.J) return a.n > 32 ? "fused_qp_f64_n64" : "fused_qp_f64_n32";  // the tile grid the problem is padded to
-  return a.n > 32 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
+  // the tile grid the problem is padded to
+  if (!a.J) return a.n > 96 ? "fused_qp_f64_n128" : a.n > 64 ? "fused_qp_f64_n96" : a.n > 32 ? "fused_qp_f64_n64" : "fused_qp_f64_n32";
+  return a.n > 96 ? "fused_mfma_f64_n128" : a.n > 64 ? "fused_mfma_f64_n96" : a.n > 32 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
 }
 
 hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t stream) {
@@ -1326,6 +1333,23 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
+  if (a.n > 64) {  // 96 / 128-variable tile grids: correctness-first instantiations (the 128 one spills), one or two waves per SIMD
+    const bool big = a.n > 96, solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE;
+    const int bw = (!big && !solve) ? 2 : 1;
+    long long bgrid = num_cus;
+    const long long bneed = (a.batch + 4 * bw - 1) / (4 * bw);
+    if (bgrid > bneed) bgrid = bneed;
+    if (bgrid < 1) bgrid = 1;
+    const dim3 bgd((unsigned)bgrid), bbd(256 * bw);
+    if (solve) {
+      if (big) { if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<8, 1, 3, false>), bgd, bbd, 0, stream, a); else hipLaunchKernelGGL((kkt_fused_solve_kernel<8, 1, 3, true>), bgd, bbd, 0, stream, a); }
+      else { if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<6, 1, 3, false>), bgd, bbd, 0, stream, a); else hipLaunchKernelGGL((kkt_fused_solve_kernel<6, 1, 3, true>), bgd, bbd, 0, stream, a); }
+    } else {
+      if (big) { if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<8, 1, 3, false>), bgd, bbd, 0, stream, a); else hipLaunchKernelGGL((kkt_fused_f64_kernel<8, 1, 3, true>), bgd, bbd, 0, stream, a); }
+      else { if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<6, 2, 3, false>), bgd, bbd, 0, stream, a); else hipLaunchKernelGGL((kkt_fused_f64_kernel<6, 2, 3, true>), bgd, bbd, 0, stream, a); }
+    }
+    return hipGetLastError();
+  }
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
     const int swps = a.n > 32 ? 2 : 3;
     long long sgrid = num_cus;

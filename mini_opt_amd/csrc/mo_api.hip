@@ -103,6 +103,9 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
   } else if (!force_generic && mo::fused_f32_supported(a, plan->desc.dtype)) {
     MO_HIP_CHECK(mo::launch_fused_f32(a, plan->num_cus, s));
   } else {
+    if (plan->generic_lds > 160 * 1024)
+      return fail(MO_ERR_UNSUPPORTED, "this call needs the generic kernel (mode %d, flags 0x%x, layout or alignment outside the fused kernels' range) "
+                  "but the problem needs %zu B of LDS there (> 160 KiB)", a.mode, a.flags, plan->generic_lds);
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
   return MO_OK;
@@ -188,7 +191,9 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   memset(&a, 0, sizeof(a));
   a.n = desc->n; a.k = desc->k; a.m = desc->m; a.m_r = desc->m_r;
   p->generic_lds = mo::generic_lds_bytes(a, p->elem);
-  if (p->generic_lds > 160 * 1024) {
+  // fp64 systems up to n = 128 (k <= 14, m <= 64) run on the fused kernels even when the LDS-resident generic kernel cannot hold them
+  const bool fused_capable = desc->dtype == MO_F64 && desc->n <= 128 && desc->k <= 14 && desc->m <= 64;
+  if (p->generic_lds > 160 * 1024 && !fused_capable) {
     const size_t need = p->generic_lds;
     (void)hipFree(p->ticket);
     delete p;

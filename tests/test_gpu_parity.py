@@ -678,3 +678,52 @@ def test_fused_vs_generic_random_shapes():
         if conv.any():
             xa, xb_ = f[4][conv][:, :n], g_[4][conv][:, :n]
             assert np.max(np.abs(xa - xb_)) <= 1e-5 * max(1.0, np.max(np.abs(xb_))), tag
+
+
+@pytest.mark.parametrize("n,k,m,m_r,level", [(66, 4, 10, 72, "J"), (96, 8, 32, 192, "J"), (100, 14, 64, 200, "J"), (128, 10, 40, 256, "J"),
+                                             (81, 3, 20, 0, "QP"), (128, 14, 64, 0, "QP")])
+def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
+    """The 96- and 128-variable tile grids of the fp64 fused kernels (sizes the LDS-resident generic kernel cannot hold at all once
+    n + k > 141): Newton step against the oracle, and the whole Solve against the oracle's Solve."""
+    rng = np.random.default_rng(n * 7 + k)
+    B = 7
+    mr = m_r if m_r else 2 * n
+    J = rng.uniform(-1, 1, (B, mr, n)); r = rng.uniform(-1, 1, (B, mr))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32)
+    ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n))
+    sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    assert level == "QP" or vars_.shape[1] % 2 == 0
+    mu = np.full(B, 0.05)
+    lam = 1e-3
+    G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    c = np.einsum("bqi,bq->bi", J, r)
+    common = dict(A_eq=T(A), b_eq=T(b), cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    if level == "J":
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common)
+    else:
+        prob = Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), **common)
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused"), s.step_kernel()
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, G=np.tril(G).transpose(0, 2, 1).copy(), c=c, A_eq=A, b_eq=b, cons_var=cv,
+                                                            cons_a=ca, cons_b=cb, vars_=vars_, mu=mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-9
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED)
+    out = s.Solve(Q.Params(**kw))
+    assert torch.all(out.status == 0)
+    v = s.variables().cpu().numpy(); nit = out.num_iterations.cpu().numpy(); tm = out.termination_state.cpu().numpy()
+    agree = 0
+    for p in range(B):
+        o = orc.Solver(orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p]))
+        term, its = o.solve(**kw)
+        if tm[p] == term and nit[p] == len(its):
+            agree += 1
+            if term == Q.SATISFIED_KKT_TOL:
+                np.testing.assert_allclose(v[p][:n], o.variables[:n], rtol=1e-6, atol=1e-8)
+    assert agree >= B - 1
