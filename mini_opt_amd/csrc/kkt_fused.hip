@@ -1380,9 +1380,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
 #define MO_FUSED_LAUNCH(NT_, WPS_, SW_) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, SW_, false>), gd, bd, 0, stream, a)
 #define MO_FUSED_BY_SW(NT_, WPS_)                     \
   do {                                                \
-    if (sw == 0) MO_FUSED_LAUNCH(NT_, WPS_, 0);       \
-    else if (sw == 1) MO_FUSED_LAUNCH(NT_, WPS_, 1);  \
-    else if (sw == 2) MO_FUSED_LAUNCH(NT_, WPS_, 2);  \
+    if (sw == 1) MO_FUSED_LAUNCH(NT_, WPS_, 1);       \
     else MO_FUSED_LAUNCH(NT_, WPS_, 3);               \
   } while (0)
   if (a.n > 32) {
