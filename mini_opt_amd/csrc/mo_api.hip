@@ -103,9 +103,10 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
   } else if (!force_generic && mo::fused_f32_supported(a, plan->desc.dtype)) {
     MO_HIP_CHECK(mo::launch_fused_f32(a, plan->num_cus, s));
   } else {
-    if (plan->generic_lds > 160 * 1024)
+    const size_t need = mo::generic_lds_bytes(a, plan->elem);
+    if (need > 160 * 1024)
       return fail(MO_ERR_UNSUPPORTED, "this call needs the generic kernel (mode %d, flags 0x%x, layout or alignment outside the fused kernels' range) "
-                  "but the problem needs %zu B of LDS there (> 160 KiB)", a.mode, a.flags, plan->generic_lds);
+                  "but the problem needs %zu B of LDS there (> 160 KiB)", a.mode, a.flags, need);
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
   return MO_OK;

@@ -727,3 +727,26 @@ def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
             if term == Q.SATISFIED_KKT_TOL:
                 np.testing.assert_allclose(v[p][:n], o.variables[:n], rtol=1e-6, atol=1e-8)
     assert agree >= B - 1
+
+
+def test_large_fp64_plan_falls_back_cleanly():
+    """n = 128, k = 14 in fp64 does not fit the LDS-resident generic kernel: calls the fused kernels cannot serve return
+    MO_ERR_UNSUPPORTED with a message instead of launching; the fused-capable calls work."""
+    rng = np.random.default_rng(1)
+    n, k, m, m_r, B = 128, 14, 4, 256, 3
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = np.ones((B, m)); cb = np.ones((B, m))
+    vars_ = np.concatenate([np.zeros((B, n)), np.ones((B, m)), np.zeros((B, k)), np.ones((B, m))], axis=1)
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=1e-3, A_eq=T(A), b_eq=T(b), cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    s = Q.QPInteriorPointSolver(prob)
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(0.1, 0.995)
+    assert torch.all(status == 0) and torch.isfinite(delta).all()
+    with pytest.raises(L.MiniOptError) as e:
+        s.NewtonStep(0.1, 0.995, include_inequalities=False)       # MO_STEP_NO_INEQUALITIES lives on the generic kernel only
+    assert "LDS" in str(e.value)
+    with pytest.raises(L.MiniOptError):
+        Q.QPInteriorPointSolver(prob, force_generic=True).NewtonStep(0.1, 0.995)
+    G, c, half = Q.linearize(prob)                                   # n = 128 alone still fits the generic kernel (k = m = 0 there)
+    np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
