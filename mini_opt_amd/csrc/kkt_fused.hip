@@ -555,21 +555,27 @@ __device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k
 // ---- the kernel ------------------------------------------------------------------------------------------------
 // NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 14, m <= 64, m_r % 4 == 0 are
 // checked by fused_supported().
-template <int NT, int WPS> struct FusedCfg {
+// MC = constraint slots per lane (m <= 64 MC).
+template <int NT, int WPS, int MC = 1> struct FusedCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;                 // 16-byte J loads per lane per 4-row group
   static constexpr int DPS = NH + 1;                // LDS-DMA instructions per 4-row group (J pieces + 32 B of r)
   static constexpr int SLOT = NH * 1024 + 64;       // ring slot: 4 rows of J (lane-linear) + r[4s..4s+3]
-  static constexpr int D = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 7) : (WPS >= 4 ? 4 : 8));  // ring depth (4-row groups in flight per wave), LDS-limited
-  static constexpr int VEC = (3 * N + 4 * 64 + 32 + 32) * 8;  // xs, diagS|rp, rhsS|dxs, cons a/b/s/z [64], cons var [64 int], y[16], b_eq[16]
+  static constexpr int MCAP = 64 * MC;
+  static constexpr int VEC = (3 * N + 4 * MCAP + MCAP / 2 + 32) * 8;  // xs, diagS|rp, rhsS|dxs, cons a/b/s/z, cons var (int), y[16], b_eq[16]
+  static constexpr int D_FIT = ((160 * 1024) / (4 * WPS) - VEC) / SLOT;  // what the 160 KiB of a CU leave per wave
+  static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 7) : (WPS >= 4 ? 4 : 8));
+  static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);  // ring depth (4-row groups in flight per wave), LDS-limited
+  static_assert(D >= 2, "LDS budget");
   static constexpr int LDS = D * SLOT + VEC;
 };
 
 // One workgroup of 4*WPS independent waves per CU (so that exactly WPS waves sit on every SIMD).  The waves never
 // synchronise with each other; each owns its slice of the workgroup's LDS.
-template <int NT, int WPS, int SW, bool QPL>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
-  using C = FusedCfg<NT, WPS>;
+  using C = FusedCfg<NT, WPS, MC>;
+  constexpr int MCAP = C::MCAP;
   constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
 
@@ -583,11 +589,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   double* const rp = diagS;                                       // right-hand side, permuted order (diagS is dead by then)
   double* const dxs = rhsS;                                       // dx, natural order (rhsS is dead by then)
   double* const cA = rhsS + N;                                    // per-constraint a, b, s, z and variable index; y; b_eq:
-  double* const cB = cA + 64;                                     //   LDS-DMA targets of P0 (the small per-problem vectors
-  double* const cS = cB + 64;                                     //   cost no VGPRs while J streams)
-  double* const cZ = cS + 64;
-  int* const cV = reinterpret_cast<int*>(cZ + 64);
-  double* const yb = cZ + 64 + 32;
+  double* const cB = cA + MCAP;                                   //   LDS-DMA targets of P0 (the small per-problem vectors
+  double* const cS = cB + MCAP;                                   //   cost no VGPRs while J streams)
+  double* const cZ = cS + MCAP;
+  int* const cV = reinterpret_cast<int*>(cZ + MCAP);
+  double* const yb = cZ + MCAP + MCAP / 2;
   double* const bb = yb + 16;
   const unsigned ring_base = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (low 32 bits of the flat address)
   const unsigned vec_base = ring_base + D * SLOT;                 // LDS byte address of xs
@@ -663,15 +669,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     dma_doubles(vp, vec_base, nn, lane);                                                    // x -> xs
     if (m > 0) {
       const long long coff = p * ka->cons_stride;
-      if (lane < m) dma4_s(ka->cons_var + coff, 4u * (unsigned)lane, vec_base + (3 * N + 256) * 8);
+      if (lane < m) dma4_s(ka->cons_var + coff, 4u * (unsigned)lane, vec_base + (3 * N + 4 * MCAP) * 8);
+      if (MC > 1 && lane + 64 < m) dma4_s(ka->cons_var + coff + 64, 4u * (unsigned)lane, vec_base + (3 * N + 4 * MCAP) * 8 + 256);
       dma_doubles((const double*)ka->cons_a + coff, vec_base + (3 * N) * 8, m, lane);
-      dma_doubles((const double*)ka->cons_b + coff, vec_base + (3 * N + 64) * 8, m, lane);
-      dma_doubles(vp + nn, vec_base + (3 * N + 128) * 8, m, lane);                           // s
-      dma_doubles(vp + nn + m + k, vec_base + (3 * N + 192) * 8, m, lane);                   // z
+      dma_doubles((const double*)ka->cons_b + coff, vec_base + (3 * N + MCAP) * 8, m, lane);
+      dma_doubles(vp + nn, vec_base + (3 * N + 2 * MCAP) * 8, m, lane);                      // s
+      dma_doubles(vp + nn + m + k, vec_base + (3 * N + 3 * MCAP) * 8, m, lane);              // z
     }
     if (k > 0) {
-      dma_doubles(vp + nn + m, vec_base + (3 * N + 288) * 8, k, lane);                       // y
-      dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 304) * 8, k, lane);  // b_eq
+      dma_doubles(vp + nn + m, vec_base + (3 * N + 4 * MCAP + MCAP / 2) * 8, k, lane);       // y
+      dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 4 * MCAP + MCAP / 2 + 16) * 8, k, lane);  // b_eq
     }
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
     load_a_tiles<NT, QPL>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, nn, g, j, U);
@@ -701,19 +708,32 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
       rhsS[2 * lane] = 0.0; rhsS[2 * lane + 1] = 0.0;
     }
-    int cvar = 0; double ca = 1.0, cb = 0.0, cs = 1.0, cz = 0.0;
-    if (lane < m) { cvar = cV[lane]; ca = cA[lane]; cb = cB[lane]; cs = cS[lane]; cz = cZ[lane]; }
-    lds_fence();  // diagS / rhsS initialised
-    bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= nn));
-    if (bad_index) cvar = 0;
-    const bool slack_bad = __any((lane < m) && !(cs > 0.0));
-    const bool any_bad_index = __any(bad_index);
-    const double cs_inv = rcp_f64(cs);                               // 1/s to ~1 ulp (two Newton steps on v_rcp_f64)
-    if (lane < m) {
-      const double zs = cz * cs_inv;
-      atomicAdd(&diagS[cvar], ca * zs * ca);                         // qp.cc:296
-      atomicAdd(&rhsS[cvar], ca * (cz * (cs - cb) + mu) * cs_inv);    // x+ form of qp.cc:340-341
+    int cvar[MC]; double ca[MC], cb[MC], cs[MC], cz[MC], cs_inv[MC];  // constraint lane + 64 ci
+    bool bad_index[MC];
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) {
+      const int ix = lane + 64 * ci;
+      cvar[ci] = 0; ca[ci] = 1.0; cb[ci] = 0.0; cs[ci] = 1.0; cz[ci] = 0.0;
+      if (ix < m) { cvar[ci] = cV[ix]; ca[ci] = cA[ix]; cb[ci] = cB[ix]; cs[ci] = cS[ix]; cz[ci] = cZ[ix]; }
     }
+    lds_fence();  // diagS / rhsS initialised
+    bool lane_bad_slack = false, lane_bad_index = false;
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) {
+      const int ix = lane + 64 * ci;
+      bad_index[ci] = (ix < m) && ((cvar[ci] < 0) || (cvar[ci] >= nn));
+      if (bad_index[ci]) cvar[ci] = 0;
+      lane_bad_index = lane_bad_index || bad_index[ci];
+      lane_bad_slack = lane_bad_slack || ((ix < m) && !(cs[ci] > 0.0));
+      cs_inv[ci] = rcp_f64(cs[ci]);                                  // 1/s to ~1 ulp (two Newton steps on v_rcp_f64)
+      if (ix < m) {
+        const double zs = cz[ci] * cs_inv[ci];
+        atomicAdd(&diagS[cvar[ci]], ca[ci] * zs * ca[ci]);                                  // qp.cc:296
+        atomicAdd(&rhsS[cvar[ci]], ca[ci] * (cz[ci] * (cs[ci] - cb[ci]) + mu) * cs_inv[ci]);  // x+ form of qp.cc:340-341
+      }
+    }
+    const bool slack_bad = __any(lane_bad_slack);
+    const bool any_bad_index = __any(lane_bad_index);
     lds_fence();
     double dS[NT], rS[NT];
     ldv<NT, QPL>(diagS, j, dS);
@@ -785,17 +805,23 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     for (int c = 0; c < NT; ++c) finite = finite && (fabs(dxv[c]) < INFINITY);
     if (g == 0) stv<NT, QPL>(dxs, j, dxv);
     lds_fence();
-    double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
-    if (lane < m) {
-      const double ca = cA[lane], cb = cB[lane], cs = cS[lane], cz = cZ[lane];     // re-read: not kept live across P5
-      const int cvar = bad_index ? 0 : cV[lane];
-      const double r_pi = ca * xs[cvar] + cb - cs;                                  // qp.cc:416
-      dsv = ca * dxs[cvar] + r_pi;                                                  // qp.cc:361
-      dzv = -(cz * cs_inv) * dsv - cs_inv * (cs * cz - mu);                         // qp.cc:362
-      const double tau = ka->tau;
-      if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -tau * cs * rcp_f64(dsv);        // qp.cc:498-503
-      if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -tau * cz * rcp_f64(dzv);
-      finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
+    double dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) {
+      const int ix = lane + 64 * ci;
+      dsv[ci] = 0.0; dzv[ci] = 0.0;
+      if (ix < m) {
+        const double ca2 = cA[ix], cb2 = cB[ix], cs2 = cS[ix], cz2 = cZ[ix];       // re-read: not kept live across P5
+        const int cvar2 = bad_index[ci] ? 0 : cV[ix];
+        const double csi = MC == 1 ? cs_inv[ci] : rcp_f64(cs2);                     // one slot: kept in a register; more: recomputed
+        const double r_pi = ca2 * xs[cvar2] + cb2 - cs2;                            // qp.cc:416
+        dsv[ci] = ca2 * dxs[cvar2] + r_pi;                                          // qp.cc:361
+        dzv[ci] = -(cz2 * csi) * dsv[ci] - csi * (cs2 * cz2 - mu);                  // qp.cc:362
+        const double tau = ka->tau;
+        if (cs2 + dsv[ci] <= 0.0 && fabs(dsv[ci]) > 0.0) ap = fmin(ap, -tau * cs2 * rcp_f64(dsv[ci]));  // qp.cc:498-503
+        if (cz2 + dzv[ci] <= 0.0 && fabs(dzv[ci]) > 0.0) ad = fmin(ad, -tau * cz2 * rcp_f64(dzv[ci]));
+        finite = finite && (fabs(dsv[ci]) < INFINITY) && (fabs(dzv[ci]) < INFINITY);
+      }
     }
     ap = cross_row_min(row_min(ap));
     ad = cross_row_min(row_min(ad));
@@ -815,9 +841,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       stv_n<NT, QPL>(dp, j, nn, outv);
       if (j < k) dp[nn + m + j] = st == MO_STATUS_OK ? dyv : nanv;
     }
-    if (lane < m) {
-      dp[nn + lane] = st == MO_STATUS_OK ? dsv : nanv;
-      dp[nn + m + k + lane] = st == MO_STATUS_OK ? dzv : nanv;
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) {
+      const int ix = lane + 64 * ci;
+      if (ix < m) {
+        dp[nn + ix] = st == MO_STATUS_OK ? dsv[ci] : nanv;
+        dp[nn + m + k + ix] = st == MO_STATUS_OK ? dzv[ci] : nanv;
+      }
     }
     if (lane == 0) {
       if (ka->alpha) {
@@ -1295,7 +1325,8 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64 || a.flags != 0) return false;
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
-  if (a.k > 14 || a.m > 64 || a.m < 0) return false;
+  if (a.k > 14 || a.m < 0) return false;
+  if (a.m > (a.mode == MODE_STEP ? 128 : 64)) return false;  // the step kernel takes two constraints per lane, Solve / Iterate one
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of J, r and of the state / direction vectors
@@ -1333,6 +1364,25 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
+  if (a.mode == MODE_STEP && a.m > 64) {  // two constraint slots per lane (a box on every one of 64 variables is m = 128)
+    const int wq = a.n > 96 ? 1 : (a.n > 32 ? 2 : 3);
+    long long qgrid = num_cus;
+    const long long qneed = (a.batch + 4 * wq - 1) / (4 * wq);
+    if (qgrid > qneed) qgrid = qneed;
+    if (qgrid < 1) qgrid = 1;
+    const dim3 qgd((unsigned)qgrid), qbd(256 * wq);
+#define MO_FUSED_MC2(NT_, WPS_)                                                                                      \
+  do {                                                                                                               \
+    if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, 3, false, 2>), qgd, qbd, 0, stream, a);             \
+    else hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, 3, true, 2>), qgd, qbd, 0, stream, a);                  \
+  } while (0)
+    if (a.n > 96) MO_FUSED_MC2(8, 1);
+    else if (a.n > 64) MO_FUSED_MC2(6, 2);
+    else if (a.n > 32) MO_FUSED_MC2(4, 2);
+    else MO_FUSED_MC2(2, 3);
+#undef MO_FUSED_MC2
+    return hipGetLastError();
+  }
   if (a.n > 64) {  // 96 / 128-variable tile grids: correctness-first instantiations (the 128 one spills), one or two waves per SIMD
     const bool big = a.n > 96, solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE;
     const int bw = (!big && !solve) ? 2 : 1;

@@ -750,3 +750,46 @@ def test_large_fp64_plan_falls_back_cleanly():
         Q.QPInteriorPointSolver(prob, force_generic=True).NewtonStep(0.1, 0.995)
     G, c, half = Q.linearize(prob)                                   # n = 128 alone still fits the generic kernel (k = m = 0 there)
     np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,k,m,m_r,level", [(64, 8, 128, 128, "J"), (32, 4, 65, 64, "J"), (64, 0, 100, 0, "QP"), (20, 3, 128, 0, "QP"),
+                                             (96, 8, 128, 192, "J"), (128, 14, 90, 256, "J")])
+def test_fused_step_with_up_to_128_constraints(n, k, m, m_r, level):
+    """m > 64 (e.g. a two-sided box on every one of 64 variables): the fused step kernel carries two constraint slots per lane.
+    Against the oracle; duplicates on one variable, both signs."""
+    rng = np.random.default_rng(n + 3 * m)
+    B = 11
+    mr = m_r if m_r else 2 * n
+    J = rng.uniform(-1, 1, (B, mr, n)); r = rng.uniform(-1, 1, (B, mr))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = (np.arange(m)[None, :] // 2 % n + np.zeros((B, 1), int)).astype(np.int32)           # a box per variable, wrapping around
+    ca = np.where(np.arange(m) % 2 == 0, 1.0, -1.0)[None, :] * np.ones((B, 1)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n))
+    sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    if level == "J" and vars_.shape[1] % 2:
+        pytest.skip("odd V with J-level input")
+    mu = np.full(B, 0.05)
+    lam = 1e-3
+    G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    c = np.einsum("bqi,bq->bi", J, r)
+    common = dict(A_eq=T(A) if k else None, b_eq=T(b) if k else None, cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    prob = (Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common) if level == "J"
+            else Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), **common))
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused"), s.step_kernel()
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, G=np.tril(G).transpose(0, 2, 1).copy(), c=c, A_eq=A if k else None,
+                                                            b_eq=b if k else None, cons_var=cv, cons_a=ca, cons_b=cb, vars_=vars_, mu=mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-9
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+    # status words from the second slot: s <= 0 and a bad index beyond lane 63
+    vars2 = vars_.copy(); vars2[1, n + m - 1] = 0.0
+    cv2 = cv.copy(); cv2[2, m - 2] = n
+    prob.cons_var = T(cv2, torch.int32)
+    s2 = Q.QPInteriorPointSolver(prob); s2.SetVariables(T(vars2))
+    _, _, st2 = s2.NewtonStep(T(mu), 0.995)
+    st2 = st2.cpu().numpy()
+    assert st2[1] == L.MO_STATUS_NONPOSITIVE_SLACK and st2[2] == L.MO_STATUS_BAD_INDEX and np.all(np.delete(st2, [1, 2]) == 0)
