@@ -886,20 +886,25 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 // one-shot step kernel -- solves for the DIRECTION with the residual as right-hand side, exactly the reference's system
 // (qp.cc:255-268, 337-363), so the loop keeps Newton's self-correcting behaviour down to tight KKT tolerances.
 // All three BarrierStrategy values; PREDICTOR_CORRECTOR costs two passes (two factorisations) per iteration.
-template <int NT, int WPS> struct SolveCfg {
+template <int NT, int WPS, int MC = 1> struct SolveCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;
   static constexpr int SLOT = NH * 1024 + 64;
-  static constexpr int D = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
-  static constexpr int VEC = (6 * N + 32 + 128) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32], affine ds / dz [2][64]
+  static constexpr int MCAP = 64 * MC;                    // constraint slots: MC per lane
+  static constexpr int VEC = (6 * N + 32 + 2 * MCAP) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32], affine ds / dz [2][MCAP]
+  static constexpr int D_FIT = ((160 * 1024) / (4 * WPS) - VEC) / SLOT;
+  static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
+  static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);
+  static_assert(D >= 2, "LDS budget");
   static constexpr int LDS = D * SLOT + VEC;
 };
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
 
-template <int NT, int WPS, int SW, bool QPL>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
-  using C = SolveCfg<NT, WPS>;
+  using C = SolveCfg<NT, WPS, MC>;
+  constexpr int MCAP = C::MCAP;
   constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
 
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   double* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
   double* const tmp = rhoS + N;                                   // layout-conversion scratch (R <-> V16, natural <-> permuted)
   double* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
-  double* const affS = ysm + 32;                                  // predictor-corrector: ds_aff [0,64), dz_aff [64,128)
+  double* const affS = ysm + 32;                                  // predictor-corrector: ds_aff [0,MCAP), dz_aff [MCAP,2 MCAP)
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
   const int k = a.k, m = a.m, m_r = a.m_r;
@@ -958,28 +963,43 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // a given G already carries the LM damping
 
     // ---- constants of the problem
-    int cvar = 0; double ca = 1.0, cb = 0.0;
-    if (lane < m) {
-      cvar = a.cons_var[p * a.cons_stride + lane];
-      ca = ((const double*)a.cons_a)[p * a.cons_stride + lane];
-      cb = ((const double*)a.cons_b)[p * a.cons_stride + lane];
+    int cvar[MC]; double ca[MC], cb[MC];  // constraint lane + 64 ci
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) {
+      const int ix = lane + 64 * ci;
+      cvar[ci] = 0; ca[ci] = 1.0; cb[ci] = 0.0;
+      if (ix < m) {
+        cvar[ci] = a.cons_var[p * a.cons_stride + ix];
+        ca[ci] = ((const double*)a.cons_a)[p * a.cons_stride + ix];
+        cb[ci] = ((const double*)a.cons_b)[p * a.cons_stride + ix];
+      }
     }
     double b_col = 0.0;
     if (j < k) b_col = ((const double*)a.b + p * a.b_stride)[j];
     const double* const Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
 
     // ---- state: x in the permuted V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
-    double xv[NT], yv = 0.0, cs = 1.0, cz = 1.0;
+    double xv[NT], yv = 0.0, cs[MC], cz[MC];
 #pragma unroll
     for (int c = 0; c < NT; ++c) xv[c] = 0.0;
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) { cs[ci] = 1.0; cz[ci] = 1.0; }
     const bool iterate_mode = a.mode == MODE_ITERATE;  // one Iterate (qp.cc:153-201) on the caller's state and mu
     if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
       ldv_n<NT, QPL>(vp, j, nn, xv);
       if (j < k) yv = vp[nn + m + j];
-      if (lane < m) { cs = vp[nn + lane]; cz = vp[nn + m + k + lane]; }
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci)
+        if (lane + 64 * ci < m) { cs[ci] = vp[nn + lane + 64 * ci]; cz[ci] = vp[nn + m + k + lane + 64 * ci]; }
     }
-    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= nn)));
-    if (bad_index) cvar = 0;
+    bool lane_bad_index = false;
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci) lane_bad_index = lane_bad_index || ((lane + 64 * ci < m) && ((cvar[ci] < 0) || (cvar[ci] >= nn)));
+    const bool bad_index = __any(lane_bad_index);
+    if (bad_index) {
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci) cvar[ci] = 0;
+    }
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
     int term = MO_MAX_ITERATIONS, it = 0;
@@ -992,23 +1012,31 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       if (g == 0) stv<NT, QPL>(xs, j, xv);
       lds_fence();
       for (int c = 0; c < m; ++c) {  // wave-uniform loop; one constraint at a time keeps the reference's order
-        if (lane == c) {
-          const double x0 = xs[cvar];
-          double x1;
-          if (ca < 0.0) { const double lim = cb / -ca; x1 = x0 < lim ? x0 : lim; }  // ClampX, qp.hpp:43-53
-          else { const double lim = -cb / ca; x1 = x0 > lim ? x0 : lim; }
-          xs[cvar] = x1;
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          if (lane + 64 * ci == c) {
+            const double x0 = xs[cvar[ci]];
+            double x1;
+            if (ca[ci] < 0.0) { const double lim = cb[ci] / -ca[ci]; x1 = x0 < lim ? x0 : lim; }  // ClampX, qp.hpp:43-53
+            else { const double lim = -cb[ci] / ca[ci]; x1 = x0 > lim ? x0 : lim; }
+            xs[cvar[ci]] = x1;
+          }
         }
         lds_fence();
       }
       ldv<NT, QPL>(xs, j, xv);
-      if (lane < m) {
-        const double sv = ca * xs[cvar] + cb;
-        cs = sv > 1.0e-9 ? sv : 1.0e-9;
-        cz = 1.0 / cs;
+      double sz = 0.0;
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci) {
+        if (lane + 64 * ci < m) {
+          const double sv = ca[ci] * xs[cvar[ci]] + cb[ci];
+          cs[ci] = sv > 1.0e-9 ? sv : 1.0e-9;
+          cz[ci] = 1.0 / cs[ci];
+          sz += cs[ci] * cz[ci];
+        }
       }
       if (sp.initialize_mu_with_complementarity) {  // qp.cc:115
-        const double t = wave_sum_f64(lane < m ? cs * cz : 0.0);
+        const double t = wave_sum_f64(sz);
         mu = m > 0 ? t / (double)m : 0.0;
       }
     };
@@ -1086,11 +1114,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       lds_fence();
-      double r_pi = 0.0, r_comp = 0.0;
-      if (include_ineq && lane < m) {
-        atomicAdd(&azS[cvar], ca * cz);                      // qp.cc:415
-        r_pi = ca * xs[cvar] + cb - cs;                      // qp.cc:416
-        r_comp = cs * cz;                                    // qp.cc:417
+      double r_pi[MC], r_comp[MC];
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci) {
+        r_pi[ci] = 0.0; r_comp[ci] = 0.0;
+        if (include_ineq && lane + 64 * ci < m) {
+          atomicAdd(&azS[cvar[ci]], ca[ci] * cz[ci]);                    // qp.cc:415
+          r_pi[ci] = ca[ci] * xs[cvar[ci]] + cb[ci] - cs[ci];            // qp.cc:416
+          r_comp[ci] = cs[ci] * cz[ci];                                  // qp.cc:417
+        }
       }
       // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
       // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
@@ -1134,9 +1166,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         for (int c = 0; c < NT; ++c) t = fma(r_d[c], r_d[c], t);
         n_rd2 = row_sum(t);
         n_rpe2 = row_sum(r_pe * r_pe);
-        n_rc2 = wave_sum_f64(r_comp * r_comp);
-        n_rc1 = wave_sum_f64(r_comp);
-        n_rpi2 = wave_sum_f64(r_pi * r_pi);
+        double s_rc2 = 0.0, s_rc1 = 0.0, s_rpi2 = 0.0;
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) { s_rc2 = fma(r_comp[ci], r_comp[ci], s_rc2); s_rc1 += r_comp[ci]; s_rpi2 = fma(r_pi[ci], r_pi[ci], s_rpi2); }
+        n_rc2 = wave_sum_f64(s_rc2);
+        n_rc1 = wave_sum_f64(s_rc1);
+        n_rpi2 = wave_sum_f64(s_rpi2);
         n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
       }
       if (!guess_pass && !iterate_mode && !corrector_pass) {
@@ -1173,15 +1208,26 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
       const bool predictor_pass = use_pc && !guess_pass && !corrector_pass;
       const double mu_step = m > 0 ? (predictor_pass ? 0.0 : (corrector_pass ? mu_pc : mu)) : 0.0;  // qp.cc:165-187
-      const double aff = (corrector_pass && lane < m) ? affS[lane] * affS[64 + lane] : 0.0;       // ds_aff dz_aff, qp.cc:341
-      double cs_inv = 1.0;
+      double aff[MC], cs_inv[MC];
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci) {
+        const int ix = lane + 64 * ci;
+        aff[ci] = (corrector_pass && ix < m) ? affS[ix] * affS[MCAP + ix] : 0.0;                  // ds_aff dz_aff, qp.cc:341
+        cs_inv[ci] = 1.0;
+      }
       if (include_ineq) {
-        if (__any((lane < m) && !(cs > 0.0))) { st = MO_STATUS_NONPOSITIVE_SLACK; break; }  // qp.cc:285
-        cs_inv = rcp_f64(cs);
-        if (lane < m) {
-          const double zs = cz * cs_inv;
-          atomicAdd(&diagS[cvar], ca * zs * ca);                                          // qp.cc:296
-          atomicAdd(&rhoS[cvar], ca * zs * r_pi + ca * (r_comp + aff - mu_step) * cs_inv);  // qp.cc:340-341
+        bool lane_bad_slack = false;
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) lane_bad_slack = lane_bad_slack || ((lane + 64 * ci < m) && !(cs[ci] > 0.0));
+        if (__any(lane_bad_slack)) { st = MO_STATUS_NONPOSITIVE_SLACK; break; }  // qp.cc:285
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          cs_inv[ci] = rcp_f64(cs[ci]);
+          if (lane + 64 * ci < m) {
+            const double zs = cz[ci] * cs_inv[ci];
+            atomicAdd(&diagS[cvar[ci]], ca[ci] * zs * ca[ci]);                                                        // qp.cc:296
+            atomicAdd(&rhoS[cvar[ci]], ca[ci] * zs * r_pi[ci] + ca[ci] * (r_comp[ci] + aff[ci] - mu_step) * cs_inv[ci]);  // qp.cc:340-341
+          }
         }
       }
       lds_fence();
@@ -1237,23 +1283,34 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         stv<NT, QPL>(tmp, j, dxn);  // dx, natural order
       }
       lds_fence();
-      double dsv = 0.0, dzv = 0.0, ap = 1.0, ad = 1.0;
-      if (lane < m) {
-        dsv = ca * tmp[cvar] + r_pi;                                                   // qp.cc:361
-        dzv = -(cz * cs_inv) * dsv - cs_inv * (r_comp + aff - mu_step);                // qp.cc:362
-        const double tau = predictor_pass ? 1.0 : 0.995;                               // qp.cc:174, 192
-        if (cs + dsv <= 0.0 && fabs(dsv) > 0.0) ap = -tau * cs * rcp_f64(dsv);         // qp.cc:498-503
-        if (cz + dzv <= 0.0 && fabs(dzv) > 0.0) ad = -tau * cz * rcp_f64(dzv);
-        finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
+      double dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci) {
+        dsv[ci] = 0.0; dzv[ci] = 0.0;
+        if (lane + 64 * ci < m) {
+          dsv[ci] = ca[ci] * tmp[cvar[ci]] + r_pi[ci];                                                 // qp.cc:361
+          dzv[ci] = -(cz[ci] * cs_inv[ci]) * dsv[ci] - cs_inv[ci] * (r_comp[ci] + aff[ci] - mu_step);  // qp.cc:362
+          const double tau = predictor_pass ? 1.0 : 0.995;                                             // qp.cc:174, 192
+          if (cs[ci] + dsv[ci] <= 0.0 && fabs(dsv[ci]) > 0.0) ap = fmin(ap, -tau * cs[ci] * rcp_f64(dsv[ci]));  // qp.cc:498-503
+          if (cz[ci] + dzv[ci] <= 0.0 && fabs(dzv[ci]) > 0.0) ad = fmin(ad, -tau * cz[ci] * rcp_f64(dzv[ci]));
+          finite = finite && (fabs(dsv[ci]) < INFINITY) && (fabs(dzv[ci]) < INFINITY);
+        }
       }
       if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
       ap = cross_row_min(row_min(ap));
       ad = cross_row_min(row_min(ad));
       if (predictor_pass) {
         probe_p = ap; probe_d = ad;                                                    // alpha_probe, qp.cc:174
-        if (lane < m) { affS[lane] = dsv; affS[64 + lane] = dzv; }                     // delta_affine_, qp.cc:177
-        const double sdz = wave_sum_f64(lane < m ? cs * dzv : 0.0), zds = wave_sum_f64(lane < m ? cz * dsv : 0.0),
-                     dsdz = wave_sum_f64(lane < m ? dsv * dzv : 0.0);
+        double t_sdz = 0.0, t_zds = 0.0, t_dsdz = 0.0;
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          const int ix = lane + 64 * ci;
+          if (ix < m) {
+            affS[ix] = dsv[ci]; affS[MCAP + ix] = dzv[ci];                               // delta_affine_, qp.cc:177
+            t_sdz = fma(cs[ci], dzv[ci], t_sdz); t_zds = fma(cz[ci], dsv[ci], t_zds); t_dsdz = fma(dsv[ci], dzv[ci], t_dsdz);
+          }
+        }
+        const double sdz = wave_sum_f64(t_sdz), zds = wave_sum_f64(t_zds), dsdz = wave_sum_f64(t_dsdz);
         double ma = mu;                                                                // qp.cc:519-537
         ma += ad * sdz / (double)m;
         ma += ap * zds / (double)m;
@@ -1271,15 +1328,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
       for (int c = 0; c < NT; ++c) xv[c] = fma(xb[c], ap, xv[c]);
       yv = fma(dyv, ad, yv);
-      cs = fma(dsv, ap, cs);
-      cz = fma(dzv, ad, cz);
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci) { cs[ci] = fma(dsv[ci], ap, cs[ci]); cz[ci] = fma(dzv[ci], ad, cz[ci]); }
       mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
       ++it;
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
         if (a.delta) {
           double* dp = (double*)a.delta + p * a.delta_stride;
           for (int i = lane; i < nn; i += 64) dp[i] = tmp[i];  // dx, natural order
-          if (lane < m) { dp[nn + lane] = dsv; dp[nn + m + k + lane] = dzv; }
+#pragma unroll
+          for (int ci = 0; ci < MC; ++ci)
+            if (lane + 64 * ci < m) { dp[nn + lane + 64 * ci] = dsv[ci]; dp[nn + m + k + lane + 64 * ci] = dzv[ci]; }
           if (g == 0 && j < k) dp[nn + m + j] = dyv;
         }
         if (a.ip_out && lane == 0) {
@@ -1296,7 +1355,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       stv_n<NT, QPL>(vp, j, nn, xv);
       if (j < k) vp[nn + m + j] = yv;
     }
-    if (lane < m) { vp[nn + lane] = cs; vp[nn + m + k + lane] = cz; }
+#pragma unroll
+    for (int ci = 0; ci < MC; ++ci)
+      if (lane + 64 * ci < m) { vp[nn + lane + 64 * ci] = cs[ci]; vp[nn + m + k + lane + 64 * ci] = cz[ci]; }
     const double ymin = row_min((j < k) ? yv : INFINITY), yabs = -row_min((j < k) ? -fabs(yv) : INFINITY);
     if (lane == 0) {
       if (a.termination) a.termination[p] = term;
@@ -1326,7 +1387,8 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.k > 14 || a.m < 0) return false;
-  if (a.m > (a.mode == MODE_STEP ? 128 : 64)) return false;  // the step kernel takes two constraints per lane, Solve / Iterate one
+  // two constraint slots per lane (m <= 128): the step kernel on every tile grid, Solve / Iterate on the 32 / 64 grids
+  if (a.m > ((a.mode == MODE_STEP || a.n <= 64) ? 128 : 64)) return false;
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of J, r and of the state / direction vectors
@@ -1381,6 +1443,22 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     else if (a.n > 32) MO_FUSED_MC2(4, 2);
     else MO_FUSED_MC2(2, 3);
 #undef MO_FUSED_MC2
+    return hipGetLastError();
+  }
+  if (a.m > 64) {  // Solve / Iterate with two constraint slots per lane (n <= 64, checked by fused_supported)
+    const int wq = a.n > 32 ? 2 : 3;
+    long long qgrid = num_cus;
+    const long long qneed = (a.batch + 4 * wq - 1) / (4 * wq);
+    if (qgrid > qneed) qgrid = qneed;
+    if (qgrid < 1) qgrid = 1;
+    const dim3 qgd((unsigned)qgrid), qbd(256 * wq);
+    if (a.n > 32) {
+      if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false, 2>), qgd, qbd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, true, 2>), qgd, qbd, 0, stream, a);
+    } else {
+      if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, false, 2>), qgd, qbd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, true, 2>), qgd, qbd, 0, stream, a);
+    }
     return hipGetLastError();
   }
   if (a.n > 64) {  // 96 / 128-variable tile grids: correctness-first instantiations (the 128 one spills), one or two waves per SIMD

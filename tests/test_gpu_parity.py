@@ -793,3 +793,59 @@ def test_fused_step_with_up_to_128_constraints(n, k, m, m_r, level):
     _, _, st2 = s2.NewtonStep(T(mu), 0.995)
     st2 = st2.cpu().numpy()
     assert st2[1] == L.MO_STATUS_NONPOSITIVE_SLACK and st2[2] == L.MO_STATUS_BAD_INDEX and np.all(np.delete(st2, [1, 2]) == 0)
+
+
+@pytest.mark.parametrize("n,k,m,m_r,level", [(64, 8, 128, 128, "J"), (32, 4, 70, 64, "J"), (50, 0, 100, 0, "QP"), (10, 2, 128, 0, "QP")])
+@pytest.mark.parametrize("strategy", [Q.COMPLEMENTARITY, Q.PREDICTOR_CORRECTOR])
+def test_fused_solve_with_up_to_128_constraints(n, k, m, m_r, level, strategy):
+    """Solve and Iterate with m > 64 on the 32 / 64 tile grids (two constraint slots per lane), fused vs generic kernel and -- for
+    the iteration records of a few problems -- vs the oracle."""
+    rng = np.random.default_rng(n + 5 * m + strategy)
+    B = 9
+    mr = m_r if m_r else 2 * n
+    J = rng.uniform(-1, 1, (B, mr, n)); r = rng.uniform(-1, 1, (B, mr))
+    A = rng.uniform(-1, 1, (B, n, k)); b = 0.1 * rng.uniform(-1, 1, (B, k))
+    cv = (np.arange(m)[None, :] // 2 % n + np.zeros((B, 1), int)).astype(np.int32)
+    ca = np.where(np.arange(m) % 2 == 0, 1.0, -1.0)[None, :] * np.ones((B, 1)); cb = rng.uniform(1.0, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n))
+    sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    if level == "J" and vars_.shape[1] % 2:
+        pytest.skip("odd V with J-level input")
+    mu = np.full(B, 0.05)
+    lam = 1e-3
+    G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    c = np.einsum("bqi,bq->bi", J, r)
+    common = dict(A_eq=T(A) if k else None, b_eq=T(b) if k else None, cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    prob = (Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common) if level == "J"
+            else Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), **common))
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12, barrier_strategy=strategy,
+              initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+    res = {}
+    for force in (False, True):
+        s = Q.QPInteriorPointSolver(prob, force_generic=force)
+        s.SetVariables(T(vars_))
+        ip, st = s.Iterate(T(mu), strategy)
+        assert torch.all(st == 0)
+        after = s.variables().cpu().numpy().copy()
+        out = s.Solve(Q.Params(**kw))
+        assert torch.all(out.status == 0)
+        res[force] = (ip.cpu().numpy(), after, s.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(),
+                      out.termination_state.cpu().numpy(), out.iterations.cpu().numpy())
+    f, g_ = res[False], res[True]
+    np.testing.assert_allclose(f[0], g_[0], rtol=1e-7, atol=1e-10, equal_nan=True)
+    np.testing.assert_allclose(f[1], g_[1], rtol=1e-8, atol=1e-10)
+    assert np.array_equal(f[3], g_[3]) and np.array_equal(f[4], g_[4])
+    conv = f[4] == Q.SATISFIED_KKT_TOL
+    assert conv.mean() > 0.6
+    np.testing.assert_allclose(f[2][conv][:, :n], g_[2][conv][:, :n], rtol=1e-6, atol=1e-8)
+    for p in range(3):  # iteration records against the oracle
+        o = orc.Solver(orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p]))
+        term, its = o.solve(**kw)
+        assert f[4][p] == term and f[3][p] == len(its)
+        scale = max(max(i.kkt_initial.r_dual, i.kkt_initial.r_comp, i.kkt_initial.r_primal_ineq, i.kkt_initial.r_primal_eq) for i in its)
+        for i, itr in enumerate(its):
+            exp = [itr.kkt_initial.r_dual, itr.kkt_initial.r_comp, itr.kkt_initial.r_primal_eq, itr.kkt_initial.r_primal_ineq,
+                   itr.kkt_final.r_dual, itr.kkt_final.r_comp, itr.kkt_final.r_primal_eq, itr.kkt_final.r_primal_ineq,
+                   itr.ip.mu, itr.ip.alpha_primal, itr.ip.alpha_dual, itr.ip.alpha_probe_primal, itr.ip.alpha_probe_dual, itr.ip.mu_affine]
+            np.testing.assert_allclose(f[5][p][i], exp, rtol=1e-6, atol=1e-9 + 1e-12 * scale, equal_nan=True)
