@@ -400,8 +400,6 @@ def test_fused_edge_shapes(n, k, m, m_r):
     sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
     vars_ = np.concatenate([x, sl, y, z], axis=1)
     V = vars_.shape[1]
-    if V % 2:  # the fused kernel needs 16-byte aligned per-problem state: pad the stride by hand is not possible here -> skip
-        pytest.skip("odd V: fused path requires an even vars stride")
     mu = np.full(B, 0.05)
     lam = 0.5 if m_r < n else 1e-3                                  # rank-deficient J^T J needs the LM damping
     prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
@@ -579,8 +577,6 @@ def test_fused_padded_sizes(n, k, m, m_r, level):
     x = rng.uniform(-0.1, 0.1, (B, n))
     sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
     vars_ = np.concatenate([x, sl, y, z], axis=1)
-    if level == "J" and vars_.shape[1] % 2:
-        pytest.skip("odd V with J-level input: 16-byte alignment of the state")
     mu = np.full(B, 0.05)
     lam = 1e-3
     G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
@@ -627,8 +623,6 @@ def test_fused_vs_generic_random_shapes():
         m = int(rng.integers(0, 65))
         m_r = int(rng.integers(1, 40)) * 4
         V = n + 2 * m + k
-        if level == "J" and V % 2:
-            continue
         tried += 1
         B = 9
         J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
@@ -695,7 +689,6 @@ def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
     x = rng.uniform(-0.1, 0.1, (B, n))
     sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
     vars_ = np.concatenate([x, sl, y, z], axis=1)
-    assert level == "QP" or vars_.shape[1] % 2 == 0
     mu = np.full(B, 0.05)
     lam = 1e-3
     G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
@@ -767,8 +760,6 @@ def test_fused_step_with_up_to_128_constraints(n, k, m, m_r, level):
     x = rng.uniform(-0.1, 0.1, (B, n))
     sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
     vars_ = np.concatenate([x, sl, y, z], axis=1)
-    if level == "J" and vars_.shape[1] % 2:
-        pytest.skip("odd V with J-level input")
     mu = np.full(B, 0.05)
     lam = 1e-3
     G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
@@ -810,8 +801,6 @@ def test_fused_solve_with_up_to_128_constraints(n, k, m, m_r, level, strategy):
     x = rng.uniform(-0.1, 0.1, (B, n))
     sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
     vars_ = np.concatenate([x, sl, y, z], axis=1)
-    if level == "J" and vars_.shape[1] % 2:
-        pytest.skip("odd V with J-level input")
     mu = np.full(B, 0.05)
     lam = 1e-3
     G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
