@@ -421,6 +421,7 @@ struct JStream {
   const char* rbase;   // wave-uniform: r + 4s
   unsigned joff, roff; // per-lane byte offsets inside a 4-row group / inside r[4s .. 4s+3]
   unsigned jstep;      // bytes per 4-row group (4 nn doubles)
+  const double* tail_j; const double* tail_r; int rem, row_len, g_, j_;  // the m_r % 4 rows left over after the last full group
   bool act0, act1, act2, act3;  // does this lane's piece h lie inside the row (nn < N pads the system; the ring is zeroed once)
   const char* lane_piece;
   const char* r_elem;
@@ -434,10 +435,12 @@ struct JStream {
     joff = (unsigned)(g * nn + 2 * j) * 8u;
     jstep = 32u * (unsigned)nn;
     act0 = 2 * j < nn; act1 = 32 + 2 * j < nn; act2 = 64 + 2 * j < nn; act3 = 96 + 2 * j < nn;
-    roff = 16u * (unsigned)lane_;                            // lanes 0,1 fetch r[4s .. 4s+3]
+    roff = 4u * (unsigned)lane_;                             // lanes 0..7 fetch the eight dwords of r[4s .. 4s+3] (no 16-byte alignment)
     lane_piece = smem + lane_ * 16;                          // this lane's 16 bytes inside a 1 KiB DMA piece
     r_elem = smem + NH * 1024 + 8 * g;                       // r[4s + g] inside a slot
     ring_base = ring_base_; lane = lane_; nsteps = m_r >> 2;
+    rem = m_r & 3; row_len = nn; g_ = g; j_ = j;
+    tail_j = Jp + (size_t)(4 * nsteps) * nn; tail_r = rg + 4 * nsteps;
   }
   template <int SL> __device__ inline void issue() {  // DMAs of the next not-yet-issued 4-row group into ring slot SL
     const unsigned dst = ring_base + SL * SLOT;
@@ -445,7 +448,7 @@ struct JStream {
     if (NH > 1 && act1) dma16_s<256>(jbase, joff, dst + 1024 - 256);  // the instruction offset also advances the LDS address
     if (NH > 2 && act2) dma16_s<512>(jbase, joff, dst + 2048 - 512);
     if (NH > 3 && act3) dma16_s<768>(jbase, joff, dst + 3072 - 768);
-    if (lane < 2) dma16_s<0>(rbase, roff, dst + NH * 1024);
+    if (lane < 8) dma4_s(rbase, roff, dst + NH * 1024);
     jbase += jstep;
     rbase += 32;
   }
@@ -491,6 +494,27 @@ struct JStream {
 #define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume<(u < D ? u : 0)>(q0 + u, U, cpart);
       MO_FOR_SLOTS(MO_CONSUME)
 #undef MO_CONSUME
+    }
+    if (rem) {  // wave-uniform: up to three rows that do not fill a 4-row group -- plain loads, lanes of the missing rows feed zeros
+      double ops[NT];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) ops[c] = 0.0;
+      double rq = 0.0;
+      if (g_ < rem) {
+        const double* row = tail_j + (size_t)g_ * row_len + 2 * j_;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          if (32 * h + 2 * j_ < row_len) { const d2 v = *(const d2*)(row + 32 * h); ops[2 * h] = v[0]; ops[2 * h + 1] = v[1]; }
+        }
+        rq = tail_r[g_];
+      }
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta) {
+        cpart[ta] = fma(ops[ta], rq, cpart[ta]);
+#pragma unroll
+        for (int tb = ta; tb < NT; ++tb)
+          U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+      }
     }
   }
 #undef MO_FOR_SLOTS
@@ -1391,10 +1415,9 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of J and r (the state / direction vectors are accessed 8 bytes at a time)
-    if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
+    if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0) return false;  // m_r % 4 rows are handled after the ring stream
     if (a.n & 1) return false;  // rows of J must start on 16-byte boundaries
     if (!aligned16(a.J) || (a.J_stride & 1)) return false;
-    if (!aligned16(a.r) || (a.r_stride & 1)) return false;
   } else {    // QP-level: G, c given; no alignment requirements
     if (!a.G || !a.c || a.G_ld < a.n) return false;
   }
