@@ -464,7 +464,8 @@ struct JStream {
       default: wait_vmcnt<(D > 6 ? 6 : 0) * DPS>(); break;
     }
   }
-  template <int SL> __device__ inline void consume(int q, d4 (&U)[NB * NB], double (&cpart)[NT]) {  // group q sits in slot SL
+  double rsq;  // sum of r[4s + g]^2 seen by this lane (accumulated only by run<true>: the standalone linearisation wants 0.5 |r|^2)
+  template <int SL, bool RSQ = false> __device__ inline void consume(int q, d4 (&U)[NB * NB], double (&cpart)[NT]) {  // group q sits in slot SL
     wait_for_oldest(nsteps - 1 - q);
     double ops[NT];
 #pragma unroll
@@ -475,6 +476,7 @@ struct JStream {
     const double rq = *(const double*)(r_elem + SL * SLOT);
     lds_fence();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
     if (q + D < nsteps) issue<SL>();
+    if (RSQ) rsq = fma(rq, rq, rsq);
 #pragma unroll
     for (int ta = 0; ta < NT; ++ta) {
       cpart[ta] = fma(ops[ta], rq, cpart[ta]);
@@ -489,9 +491,11 @@ struct JStream {
     MO_FOR_SLOTS(MO_ISSUE)
 #undef MO_ISSUE
   }
+  template <bool RSQ = false>
   __device__ inline void run(d4 (&U)[NB * NB], double (&cpart)[NT]) {  // G tiles += J^T J, cpart += J^T r partials
+    if (RSQ) rsq = 0.0;
     for (int q0 = 0; q0 < nsteps; q0 += D) {
-#define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume<(u < D ? u : 0)>(q0 + u, U, cpart);
+#define MO_CONSUME(u) if (u < D && q0 + u < nsteps) consume<(u < D ? u : 0), RSQ>(q0 + u, U, cpart);
       MO_FOR_SLOTS(MO_CONSUME)
 #undef MO_CONSUME
     }
@@ -508,6 +512,7 @@ struct JStream {
         }
         rq = tail_r[g_];
       }
+      if (RSQ) rsq = fma(rq, rq, rsq);
 #pragma unroll
       for (int ta = 0; ta < NT; ++ta) {
         cpart[ta] = fma(ops[ta], rq, cpart[ta]);
@@ -899,6 +904,87 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     atomicMax(a.debug + 12, rt);
   }
 #endif
+}
+
+// =====================================================================================================================
+// Standalone linearisation (mo_linearize, the cost part of mo_fill_qp): LinearizeAndFillQP's G = J^T J + lambda I (lower triangle,
+// strict upper written as 0), c = J^T r, 0.5 |r|^2 (nonlinear.cc:182-189; residual.hpp:206-224) with the same J stream as the step
+// kernel.  The tiles leave the registers through scattered 8-byte stores (position -> natural index), 64 KB per problem at n = 64.
+template <int NT, int WPS>
+__global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(const KernelArgs a) {
+  using C = FusedCfg<NT, WPS>;
+  constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
+  constexpr int WAVES = 4 * WPS;
+  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* const smem = smem_all + wave * C::LDS;
+  const unsigned ring_base = (unsigned)(uintptr_t)smem;
+  const int nn = a.n, m_r = a.m_r;
+  for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
+  lds_fence();
+  const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  auto chunk_for = [&](long long observed) -> int {
+    const long long c = (a.batch - observed) >> chunk_shift;
+    return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
+  };
+  auto take_ticket = [&](int chunk) -> unsigned long long {
+    unsigned long long t = 0;
+    if (lane_id() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    return t;
+  };
+  auto uniform64 = [](unsigned long long v) -> long long {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  int chunk = chunk_for(0);
+  long long p = uniform64(take_ticket(chunk));
+  long long chunk_end = p + chunk;
+  while (p < a.batch) {
+    const bool last_of_chunk = p + 1 >= chunk_end;
+    int next_chunk = 0;
+    unsigned long long next_ticket = 0;
+    if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk); }
+    const int lane = lane_id();
+    const int g = lane >> 4, j = lane & 15;
+    JStream<NT, D> stream;
+    stream.init((const double*)a.J + p * a.J_stride, (const double*)a.r + p * a.r_stride, smem, ring_base, lane, g, j, m_r, nn);
+    stream.prologue();
+    d4 U[NB * NB];
+#pragma unroll
+    for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
+    double cpart[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
+    stream.template run<true>(U, cpart);
+    double cvec[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+    const double half_sq = 0.5 * cross_row_sum(stream.rsq);  // every lane of row g holds the sum over its rows 4s + g
+    const double lam_in = a.lambda_vec ? ((const double*)a.lambda_vec)[p * a.lambda_vec_stride] : a.lambda;
+    const double lam = lam_in > 0.0 ? lam_in : 0.0;  // nonlinear.cc:187-189
+    double* Go = (double*)a.G_out + p * a.G_out_stride;
+    const int ld = a.G_out_ld;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb) {
+        const int natc = 32 * (tb >> 1) + 2 * j + (tb & 1);        // variable of tile column position 16 tb + j
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = g + 4 * t;
+          const int natr = 32 * (ta >> 1) + 2 * r + (ta & 1);      // variable of tile row position 16 ta + r
+          if (natr < nn && natc < nn) {
+            const int hi = natr > natc ? natr : natc, lo = natr > natc ? natc : natr;
+            Go[hi + (size_t)lo * ld] = U[ta * NB + tb][t] + (hi == lo ? lam : 0.0);   // lower triangle (residual.hpp:216-220)
+            if (hi != lo) Go[lo + (size_t)hi * ld] = 0.0;                             // the strict upper triangle stays exactly zero
+          }
+        }
+      }
+    }
+    if (g == 0) stv_n<NT, false>((double*)a.c_out + p * a.c_out_stride, j, nn, cvec);
+    if (lane == 0 && a.half_sq_out) ((double*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = half_sq;
+    if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+  }
 }
 
 // =====================================================================================================================
@@ -1407,6 +1493,10 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64 || a.flags != 0) return false;
+  if (a.mode == MODE_LINEARIZE) {  // standalone J^T J: J-level fp64 only, same layout rules as the step kernel
+    return a.J && a.ticket && a.G_out && a.c_out && a.n >= 2 && a.n <= 128 && !(a.n & 1) && a.J_row_major && a.J_ld == a.n && a.m_r > 0 &&
+           aligned16(a.J) && !(a.J_stride & 1) && a.G_out_ld >= a.n;
+  }
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.k > 14 || a.m < 0) return false;
@@ -1446,6 +1536,19 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
+  if (a.mode == MODE_LINEARIZE) {
+    const int wl = a.n > 96 ? 1 : (a.n > 64 ? 2 : 3);
+    long long lgrid = num_cus;
+    const long long lneed = (a.batch + 4 * wl - 1) / (4 * wl);
+    if (lgrid > lneed) lgrid = lneed;
+    if (lgrid < 1) lgrid = 1;
+    const dim3 lgd((unsigned)lgrid), lbd(256 * wl);
+    if (a.n > 96) hipLaunchKernelGGL((kkt_fused_linearize_kernel<8, 1>), lgd, lbd, 0, stream, a);
+    else if (a.n > 64) hipLaunchKernelGGL((kkt_fused_linearize_kernel<6, 2>), lgd, lbd, 0, stream, a);
+    else if (a.n > 32) hipLaunchKernelGGL((kkt_fused_linearize_kernel<4, 3>), lgd, lbd, 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_linearize_kernel<2, 3>), lgd, lbd, 0, stream, a);
+    return hipGetLastError();
+  }
   if (a.mode == MODE_STEP && a.m > 64) {  // two constraint slots per lane (a box on every one of 64 variables is m = 128)
     const int wq = a.n > 96 ? 1 : (a.n > 32 ? 2 : 3);
     long long qgrid = num_cus;
