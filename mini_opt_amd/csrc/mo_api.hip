@@ -116,15 +116,19 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
 
 namespace {
 // scratch of one mo_nls_solve call, released on every exit path
-struct NlsScratch {
-  void* ptrs[24];
-  int count = 0;
-  ~NlsScratch() { for (int i = 0; i < count; ++i) (void)hipFree(ptrs[i]); }
+struct NlsScratch {  // one allocation carved into 256-byte aligned pieces
+  char* base = nullptr;
+  size_t used = 0, capacity = 0;
+  ~NlsScratch() { if (base) (void)hipFree(base); }
+  static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+  template <typename T> void reserve(size_t elems) { capacity += padded((elems ? elems : 1) * sizeof(T)); }
+  hipError_t commit() { return hipMalloc((void**)&base, capacity ? capacity : 256); }
   template <typename T> hipError_t alloc(T** out, size_t elems) {
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, (elems ? elems : 1) * sizeof(T));
-    if (e == hipSuccess) { ptrs[count++] = p; *out = (T*)p; }
-    return e;
+    const size_t bytes = padded((elems ? elems : 1) * sizeof(T));
+    if (!base || used + bytes > capacity) return hipErrorOutOfMemory;
+    *out = reinterpret_cast<T*>(base + used);
+    used += bytes;
+    return hipSuccess;
   }
 };
 }  // namespace
@@ -504,6 +508,17 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
   NlsScratch scratch;
   double *qp_vars, *cons_b, *cons_a, *errors_pre, *errors_step, *deriv, *quad, *lagrange, *sd;
   int *qp_status, *qp_term, *qp_nit, *si, *counters, *cons_var;
+  scratch.reserve<double>((size_t)batch * Vs);
+  for (int i = 0; i < 2; ++i) scratch.reserve<double>((size_t)batch * m);
+  scratch.reserve<int>((size_t)batch * m);
+  for (int i = 0; i < 3; ++i) scratch.reserve<double>((size_t)batch * 2);
+  scratch.reserve<double>((size_t)batch);
+  scratch.reserve<double>((size_t)batch * 2);
+  scratch.reserve<double>((size_t)batch * mo::NLS_SD);
+  for (int i = 0; i < 3; ++i) scratch.reserve<int>((size_t)batch);
+  scratch.reserve<int>((size_t)batch * mo::NLS_SI);
+  scratch.reserve<int>(2);
+  MO_HIP_CHECK(scratch.commit());
   MO_HIP_CHECK(scratch.alloc(&qp_vars, (size_t)batch * Vs));
   MO_HIP_CHECK(scratch.alloc(&cons_b, (size_t)batch * m));  // the QP's constraints: one stride for (variable, a, shifted b)
   MO_HIP_CHECK(scratch.alloc(&cons_a, (size_t)batch * m));
