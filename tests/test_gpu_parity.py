@@ -839,3 +839,32 @@ def test_fused_solve_with_up_to_128_constraints(n, k, m, m_r, level, strategy):
                    itr.kkt_final.r_dual, itr.kkt_final.r_comp, itr.kkt_final.r_primal_eq, itr.kkt_final.r_primal_ineq,
                    itr.ip.mu, itr.ip.alpha_primal, itr.ip.alpha_dual, itr.ip.alpha_probe_primal, itr.ip.alpha_probe_dual, itr.ip.mu_affine]
             np.testing.assert_allclose(f[5][p][i], exp, rtol=1e-6, atol=1e-9 + 1e-12 * scale, equal_nan=True)
+
+
+def test_newton_step_is_graph_capturable():
+    """mo_newton_step enqueues only a 8-byte memset and one kernel on the caller's stream: it can be captured into a HIP graph
+    (torch.cuda.graph) and replayed on new data in the same buffers."""
+    d = synth.CONFIGS["cfg2"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 64, stream=31)
+    prob = batch_to_device(hb)
+    s = Q.QPInteriorPointSolver(prob)
+    s.SetVariables(T(hb.vars))
+    mu = T(hb.mu)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        s.NewtonStep(mu, 0.995)                              # warm-up outside the capture (allocations of the Python wrapper)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        delta, alpha, status = s.NewtonStep(mu, 0.995)
+    # new state in the captured buffers, then replay
+    hb2 = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 64, stream=32)
+    s.variables().copy_(T(hb2.vars)); mu.copy_(T(hb2.mu))
+    prob.J.copy_(T(hb2.J)); prob.r.copy_(T(hb2.r)); prob.A_eq.copy_(T(hb2.A_eq)); prob.b_eq.copy_(T(hb2.b_eq))
+    prob.cons_var.copy_(T(hb2.cons_var, torch.int32)); prob.cons_a.copy_(T(hb2.cons_a)); prob.cons_b.copy_(T(hb2.cons_b))
+    graph.replay()
+    torch.cuda.synchronize()
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(hb2.n, hb2.k, hb2.m, J=hb2.J, r=hb2.r, lam=hb2.lam, A_eq=hb2.A_eq, b_eq=hb2.b_eq,
+                                                            cons_var=hb2.cons_var, cons_a=hb2.cons_a, cons_b=hb2.cons_b, vars_=hb2.vars, mu=hb2.mu)
+    assert torch.all(status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < TOL64
