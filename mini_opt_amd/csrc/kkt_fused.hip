@@ -264,7 +264,16 @@ __device__ inline void dma16(const void* gsrc, unsigned lds_dst) {
 // Scalar-base forms: global address = sbase (wave-uniform, SGPR pair) + voff (per-lane 32-bit byte offset) + IMM; the LDS
 // address is M0 + IMM + 16 * lane (the instruction offset applies to BOTH sides, found the hard way).  The address
 // arithmetic of a stream then lives on the scalar unit; the VALU (which the f64 MFMA shares) sees none of it.
-template <int IMM> __device__ inline void dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+// The base and the LDS address are wave-uniform by construction; readfirstlane says so to hipcc where its divergence analysis
+// gives up (values carried around a loop with data-dependent exits) -- it folds away when the value already sits in SGPRs.
+__device__ inline const void* uniform_ptr(const void* p) {
+  const unsigned long long b = (unsigned long long)(uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+template <int IMM> __device__ inline void dma16_s(const void* sbase_in, unsigned voff, unsigned lds_dst_in) {
+  const void* sbase = uniform_ptr(sbase_in);
+  const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
@@ -272,7 +281,9 @@ template <int IMM> __device__ inline void dma16_s(const void* sbase, unsigned vo
       : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM)
       : "memory");
 }
-__device__ inline void dma4_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+__device__ inline void dma4_s(const void* sbase_in, unsigned voff, unsigned lds_dst_in) {
+  const void* sbase = uniform_ptr(sbase_in);
+  const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
@@ -1161,6 +1172,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         o[3] = sqrt(n_rpi2);
       } else { o[1] = 0.0; o[3] = 0.0; }
     };
+    // G = J^T J + lambda I and c = J^T r do not change between the passes of one Solve: the first pass parks its tiles in a per-problem
+    // scratch (plan-owned, a.G_out; lane-linear, every lane reads back exactly what it wrote), later passes reload 22 KB instead of
+    // re-streaming 64 KB of J and redoing 320 of the 440 MFMAs (n = 64 figures).
+    constexpr int NTILES = NT * (NT + 1) / 2, TILE_SCRATCH = NTILES * 256 + NT * 64;
+    double* const Gt = (!QPL && a.G_out) ? (double*)a.G_out + (size_t)p * TILE_SCRATCH : nullptr;
+    bool tiles_cached = false;
     double mu_used = mu;   // the mu handed to the previous Iterate
     double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
     // Mehrotra predictor-corrector (qp.cc:170-187): the predictor pass solves with mu = 0 and probes alpha(tau = 1); the
@@ -1177,7 +1194,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       JStream<NT, D> stream;
-      if (!QPL) {
+      const bool stream_now = !QPL && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;  // wave-uniform, and hipcc must know it
+      if (stream_now) {
         stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
         stream.prologue();
       }
@@ -1200,7 +1218,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       double cvec[NT];
       if (QPL) {
         load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, nn, g, j, U, cvec);
-      } else {
+      } else if (stream_now) {
         double cpart[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
@@ -1212,6 +1230,26 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+        if (Gt) {  // park the tiles and c for the following passes
+          int ti = 0;
+#pragma unroll
+          for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+            for (int tb = ta; tb < NT; ++tb, ++ti) *(d4*)(Gt + ((size_t)ti * 64 + lane) * 4) = U[ta * NB + tb];
+          }
+#pragma unroll
+          for (int c = 0; c < NT; ++c) Gt[NTILES * 256 + c * 64 + lane] = cvec[c];
+          tiles_cached = true;
+        }
+      } else {  // reload what the first pass parked
+        int ti = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+          for (int tb = ta; tb < NT; ++tb, ++ti) U[ta * NB + tb] = *(const d4*)(Gt + ((size_t)ti * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) cvec[c] = Gt[NTILES * 256 + c * 64 + lane];
       }
       {  // unit diagonal for the padding variables (index >= nn): they stay at zero
         double padv[NT];

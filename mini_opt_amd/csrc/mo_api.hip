@@ -39,6 +39,7 @@ struct mo_plan {
   // scratch for mo_qp_solve with J-level input: G [max_batch][n*n], c [max_batch][n]
   void* G_scratch;
   void* c_scratch;
+  void* tile_scratch;  // fused Solve with J-level input: the G tiles + c of every problem between passes
   unsigned long long* ticket;  // device work counter of the fused kernels (zeroed on the stream before each launch)
 };
 
@@ -187,6 +188,7 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   p->elem = desc->dtype == MO_F64 ? 8 : 4;
   p->G_scratch = nullptr;
   p->c_scratch = nullptr;
+  p->tile_scratch = nullptr;
   p->ticket = nullptr;
   if (hipMalloc((void**)&p->ticket, 256) != hipSuccess) {
     delete p;
@@ -212,6 +214,7 @@ int mo_plan_destroy(mo_plan* plan) {
   if (!plan) return MO_OK;
   if (plan->G_scratch) (void)hipFree(plan->G_scratch);
   if (plan->c_scratch) (void)hipFree(plan->c_scratch);
+  if (plan->tile_scratch) (void)hipFree(plan->tile_scratch);
   if (plan->ticket) (void)hipFree(plan->ticket);
   delete plan;
   return MO_OK;
@@ -415,7 +418,19 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
     a.G_out = plan->G_scratch; a.G_out_stride = (long long)(n * n); a.G_out_ld = (int)n;
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
   }
-  return launch(plan, a, stream);  // fused Solve kernel for J-level n = 32 / 64 fp64 problems, generic kernel otherwise
+  if (a.J && use_fused && batch <= plan->desc.max_batch) {  // tile cache between the passes (optional: without it J is re-streamed)
+    const int nt = plan->desc.n > 96 ? 8 : plan->desc.n > 64 ? 6 : plan->desc.n > 32 ? 4 : 2;
+    const size_t per_problem = (size_t)(nt * (nt + 1) / 2) * 256 + (size_t)nt * 64;
+    MO_HIP_CHECK(hipSetDevice(plan->desc.device));
+    if (!plan->tile_scratch) {
+      if (hipMalloc(&plan->tile_scratch, (size_t)plan->desc.max_batch * per_problem * sizeof(double)) != hipSuccess) {
+        plan->tile_scratch = nullptr;  // not fatal: the kernel re-streams J instead
+        (void)hipGetLastError();
+      }
+    }
+    a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_problem;
+  }
+  return launch(plan, a, stream);  // fused Solve kernel (fp64, n <= 128), generic kernel otherwise
 }
 
 int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, void* x_out, int64_t x_stride,
