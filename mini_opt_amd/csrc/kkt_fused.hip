@@ -1073,6 +1073,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       next_chunk = chunk_for(p);
       next_ticket = take_ticket(next_chunk);
     }
+    if (a.skip && a.skip[p * a.skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
+      if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+      continue;
+    }
     const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
 

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
   unsigned long long gstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gstamp_prev = __builtin_amdgcn_s_memtime();
 #endif
   for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
+    if (MODE == MODE_SOLVE && a.skip && a.skip[p * a.skip_stride] >= 0) continue;  // uniform: finished in the caller's outer loop
     __syncthreads();  // previous problem's readers are done with LDS
     const T* Jp = j_level ? (const T*)a.J + p * a.J_stride : nullptr;
     const T* rp = j_level ? (const T*)a.r + p * a.r_stride : nullptr;

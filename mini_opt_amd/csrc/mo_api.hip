@@ -382,9 +382,12 @@ int mo_iterate(mo_plan* plan, const mo_problem* prob, int64_t batch, void* vars,
   return launch(plan, a, stream);
 }
 
-int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_solve_params* params, void* vars,
-                int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
-                int32_t* status, void* stream) {
+}  // extern "C"
+
+namespace {
+int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_solve_params* params, void* vars,
+                  int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
+                  int32_t* status, const int* skip, long long skip_stride, void* stream) {
   g_err[0] = 0;
   if (int rc = check_plan(plan)) return rc;
   if (!params) return fail(MO_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -405,6 +408,7 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
   a.sp = *params;
   a.termination = termination; a.num_iterations = num_iterations; a.iterations = iterations; a.lagrange = lagrange;
   a.status = status;
+  a.skip = skip; a.skip_stride = skip_stride;
   a.ticket = plan->ticket;
   const bool use_fused = !getenv("MO_FORCE_GENERIC") && !(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype);
   if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch
@@ -431,6 +435,16 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
     a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_problem;
   }
   return launch(plan, a, stream);  // fused Solve kernel (fp64, n <= 128), generic kernel otherwise
+}
+}  // namespace
+
+extern "C" {
+
+int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_solve_params* params, void* vars,
+                int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
+                int32_t* status, void* stream) {
+  return qp_solve_impl(plan, prob, batch, params, vars, vars_stride, termination, num_iterations, iterations, lagrange, status, nullptr, 0,
+                       stream);
 }
 
 int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, void* x_out, int64_t x_stride,
@@ -611,7 +625,8 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
     MO_HIP_CHECK(mo::launch_nonlinear_errors(ea, d.dtype, s));
     if (m > 0) MO_HIP_CHECK(mo::launch_shift_constraints(sa, d.dtype, s));
     // ComputeStepDirection (nonlinear.cc:216-247): the interior-point QP on device
-    if (int rc = mo_qp_solve(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, nullptr, lagrange, qp_status, stream)) return rc;
+    if (int rc = qp_solve_impl(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, nullptr, lagrange, qp_status,
+                               si + mo::NLS_SI_TERM, mo::NLS_SI, stream)) return rc;  // terminated problems are skipped
     MO_HIP_CHECK(mo::launch_cost_derivative(da, d.dtype, s));
     MO_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
     MO_HIP_CHECK(mo::launch_nls_begin_search(na, s));

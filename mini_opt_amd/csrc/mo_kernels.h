@@ -52,6 +52,8 @@ struct KernelArgs {
   // MODE_SOLVE
   mo_solve_params sp;
   int* termination; int* num_iterations; void* iterations; void* lagrange;
+  // MODE_SOLVE inside mo_nls_solve: problems whose word skip[p * skip_stride] is >= 0 have terminated and are left untouched
+  const int* skip; long long skip_stride;
   // fused kernel: device work counter (plan-owned, zeroed on the launch stream before every launch)
   unsigned long long* ticket;
   // diagnostics only (tools/phase_timer.hip builds kkt_fused.hip with MO_FUSED_STAMPS); NULL in the product
