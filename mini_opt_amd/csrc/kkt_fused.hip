@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 template <int NT, int WPS>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(const KernelArgs a) {
   using C = FusedCfg<NT, WPS>;
-  constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
+  constexpr int NB = NT + 1, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
   __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
