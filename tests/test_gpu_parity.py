@@ -868,3 +868,23 @@ def test_newton_step_is_graph_capturable():
                                                             cons_var=hb2.cons_var, cons_a=hb2.cons_a, cons_b=hb2.cons_b, vars_=hb2.vars, mu=hb2.mu)
     assert torch.all(status == 0)
     assert rel_inf_rows(delta.cpu().numpy(), ref).max() < TOL64
+
+
+@pytest.mark.parametrize("batch", [1, 2, 13])
+def test_tiny_batches_on_the_fused_kernels(batch):
+    """Fewer problems than waves in one workgroup: the ticket loop must hand out exactly `batch` problems (step, Solve, linearise)."""
+    d = synth.CONFIGS["cfg3"]
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], batch, stream=77)
+    prob = batch_to_device(hb)
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused")
+    s.SetVariables(T(hb.vars))
+    delta, alpha, status = s.NewtonStep(T(hb.mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(hb.n, hb.k, hb.m, J=hb.J, r=hb.r, lam=hb.lam, A_eq=hb.A_eq, b_eq=hb.b_eq,
+                                                            cons_var=hb.cons_var, cons_a=hb.cons_a, cons_b=hb.cons_b, vars_=hb.vars, mu=hb.mu)
+    assert torch.all(status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < TOL64
+    out = s.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12))
+    assert torch.all(out.status == 0) and torch.all(out.termination_state == Q.SATISFIED_KKT_TOL)
+    G, c, half = Q.linearize(prob)
+    np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", hb.J, hb.r), rtol=1e-12, atol=1e-12)
