@@ -171,9 +171,8 @@ template <int NT, bool QPL> __device__ inline void ldv_n(const double* arr, int 
   } else {
 #pragma unroll
     for (int h = 0; h < NT / 2; ++h) {  // two 8-byte accesses: the caller's state / direction vectors need no 16-byte alignment
-      const bool in = 32 * h + 2 * j < nn;
-      v[2 * h] = in ? arr[32 * h + 2 * j] : 0.0;
-      v[2 * h + 1] = in ? arr[32 * h + 2 * j + 1] : 0.0;
+      v[2 * h] = (32 * h + 2 * j < nn) ? arr[32 * h + 2 * j] : 0.0;
+      v[2 * h + 1] = (32 * h + 2 * j + 1 < nn) ? arr[32 * h + 2 * j + 1] : 0.0;  // an odd nn ends inside a pair
     }
   }
 }
@@ -185,7 +184,8 @@ template <int NT, bool QPL> __device__ inline void stv_n(double* arr, int j, int
   } else {
 #pragma unroll
     for (int h = 0; h < NT / 2; ++h) {
-      if (32 * h + 2 * j < nn) { arr[32 * h + 2 * j] = v[2 * h]; arr[32 * h + 2 * j + 1] = v[2 * h + 1]; }
+      if (32 * h + 2 * j < nn) arr[32 * h + 2 * j] = v[2 * h];
+      if (32 * h + 2 * j + 1 < nn) arr[32 * h + 2 * j + 1] = v[2 * h + 1];
     }
   }
 }
@@ -424,9 +424,13 @@ template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int 
 // 4-row group s fetches J(4s+g, 32h+2j .. +1) and later reads the same 16 bytes back, so the ring needs no layout: it is a
 // per-lane FIFO that costs no VGPRs.  The source addresses are scalar bases (bumped on the SALU) plus one constant per-lane
 // offset, and the ring slots are compile-time, so the per-group VALU work is the four J^T r FMAs and nothing else.
-template <int NT, int D>
+// FLAT (odd n: rows of J are not 16-byte aligned, a 16-byte piece would straddle two rows): the 4-row group is copied as ONE flat
+// run of 32 nn bytes by dword DMAs (N / 8 instructions, the ones beyond the run parked on a trash word so that the hand-counted
+// vmcnt stays exact) and each lane picks its operands out of the slot with 8-byte LDS reads, masking the columns >= nn.
+template <int NT, int D, bool FLAT = false>
 struct JStream {
-  static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, DPS = NH + 1, SLOT = NH * 1024 + 64;
+  static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, NI = FLAT ? N / 8 : NH, DPS = NI + 1, SLOT = NH * 1024 + 64;
+  static_assert((D - 1) * DPS <= 63, "vmcnt is a 6-bit counter");
   static_assert(D >= 2 && D <= 8, "ring depth");
   const char* jbase;   // wave-uniform: row 4s of J
   const char* rbase;   // wave-uniform: r + 4s
@@ -455,6 +459,21 @@ struct JStream {
   }
   template <int SL> __device__ inline void issue() {  // DMAs of the next not-yet-issued 4-row group into ring slot SL
     const unsigned dst = ring_base + SL * SLOT;
+    if (FLAT) {
+      const int run = 32 * row_len;  // bytes of the group
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (256 * i < run) {         // wave-uniform; lane 0 is always inside
+          if (256 * i + 4 * lane < run) dma4_s(jbase + 256 * i, 4u * (unsigned)lane, dst + 256 * i);
+        } else {
+          if (lane == 0) dma4_s(jbase, 0u, dst + NH * 1024 + 48);  // keeps the DMA count per group constant; lands on a trash word
+        }
+      }
+      if (lane < 8) dma4_s(rbase, roff, dst + NH * 1024);
+      jbase += jstep;
+      rbase += 32;
+      return;
+    }
     if (act0) dma16_s<0>(jbase, joff, dst);                            // at least lane 0 of every piece is inside the row
     if (NH > 1 && act1) dma16_s<256>(jbase, joff, dst + 1024 - 256);  // the instruction offset also advances the LDS address
     if (NH > 2 && act2) dma16_s<512>(jbase, joff, dst + 2048 - 512);
@@ -479,10 +498,20 @@ struct JStream {
   template <int SL, bool RSQ = false> __device__ inline void consume(int q, d4 (&U)[NB * NB], double (&cpart)[NT]) {  // group q sits in slot SL
     wait_for_oldest(nsteps - 1 - q);
     double ops[NT];
+    if (FLAT) {
+      const double* src = reinterpret_cast<const double*>(lane_piece - lane * 16 + SL * SLOT) + g_ * row_len + 2 * j_;
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const d2 v = *(const d2*)(lane_piece + SL * SLOT + h * 1024);
-      ops[2 * h] = v[0]; ops[2 * h + 1] = v[1];
+      for (int h = 0; h < NH; ++h) {
+        const double v0 = src[32 * h], v1 = src[32 * h + 1];
+        ops[2 * h] = (32 * h + 2 * j_ < row_len) ? v0 : 0.0;
+        ops[2 * h + 1] = (32 * h + 2 * j_ + 1 < row_len) ? v1 : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const d2 v = *(const d2*)(lane_piece + SL * SLOT + h * 1024);
+        ops[2 * h] = v[0]; ops[2 * h + 1] = v[1];
+      }
     }
     const double rq = *(const double*)(r_elem + SL * SLOT);
     lds_fence();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
@@ -519,7 +548,8 @@ struct JStream {
         const double* row = tail_j + (size_t)g_ * row_len + 2 * j_;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-          if (32 * h + 2 * j_ < row_len) { const d2 v = *(const d2*)(row + 32 * h); ops[2 * h] = v[0]; ops[2 * h + 1] = v[1]; }
+          if (32 * h + 2 * j_ < row_len) ops[2 * h] = row[32 * h];
+          if (32 * h + 2 * j_ + 1 < row_len) ops[2 * h + 1] = row[32 * h + 1];
         }
         rq = tail_r[g_];
       }
@@ -611,7 +641,7 @@ template <int NT, int WPS, int MC = 1> struct FusedCfg {
 
 // One workgroup of 4*WPS independent waves per CU (so that exactly WPS waves sit on every SIMD).  The waves never
 // synchronise with each other; each owns its slice of the workgroup's LDS.
-template <int NT, int WPS, int SW, bool QPL, int MC = 1>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, bool FLAT = false>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
   using C = FusedCfg<NT, WPS, MC>;
   constexpr int MCAP = C::MCAP;
@@ -694,7 +724,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const double* vp = (const double*)ka->vars + p * ka->vars_stride;
 
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
-    JStream<NT, D> stream;
+    JStream<NT, D, FLAT> stream;
     if (!QPL) {
       stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
       stream.prologue();
@@ -1021,7 +1051,7 @@ template <int NT, int WPS, int MC = 1> struct SolveCfg {
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
 
-template <int NT, int WPS, int SW, bool QPL, int MC = 1>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, bool FLAT = false>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
   using C = SolveCfg<NT, WPS, MC>;
   constexpr int MCAP = C::MCAP;
@@ -1197,7 +1227,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // kept in VGPRs across the factorisation (see the step kernel)
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
       // ---------------------------------------------------------------- part A: tiles, residual, norms
-      JStream<NT, D> stream;
+      JStream<NT, D, FLAT> stream;
       const bool stream_now = !QPL && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;  // wave-uniform, and hipcc must know it
       if (stream_now) {
         stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
@@ -1548,8 +1578,9 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of J and r (the state / direction vectors are accessed 8 bytes at a time)
     if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0) return false;  // m_r % 4 rows are handled after the ring stream
-    if (a.n & 1) return false;  // rows of J must start on 16-byte boundaries
-    if (!aligned16(a.J) || (a.J_stride & 1)) return false;
+    // odd n: rows of J are only 8-byte aligned -> the flat-group stream (32 / 64 grids, one constraint slot per lane)
+    if ((a.n & 1) && (a.n > 64 || a.m > 64)) return false;
+    if (!(a.n & 1) && (!aligned16(a.J) || (a.J_stride & 1))) return false;  // the 16-byte pieces of the even-n stream
   } else {    // QP-level: G, c given; no alignment requirements
     if (!a.G || !a.c || a.G_ld < a.n) return false;
   }
@@ -1589,6 +1620,23 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     else if (a.n > 64) hipLaunchKernelGGL((kkt_fused_linearize_kernel<6, 2>), lgd, lbd, 0, stream, a);
     else if (a.n > 32) hipLaunchKernelGGL((kkt_fused_linearize_kernel<4, 3>), lgd, lbd, 0, stream, a);
     else hipLaunchKernelGGL((kkt_fused_linearize_kernel<2, 3>), lgd, lbd, 0, stream, a);
+    return hipGetLastError();
+  }
+  if (a.J && (a.n & 1)) {  // odd n: flat-group J stream
+    const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE;
+    const int wf = (a.n > 32 && solve) ? 2 : 3;
+    long long fgrid = num_cus;
+    const long long fneed = (a.batch + 4 * wf - 1) / (4 * wf);
+    if (fgrid > fneed) fgrid = fneed;
+    if (fgrid < 1) fgrid = 1;
+    const dim3 fgd((unsigned)fgrid), fbd(256 * wf);
+    if (solve) {
+      if (a.n > 32) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false, 1, true>), fgd, fbd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, false, 1, true>), fgd, fbd, 0, stream, a);
+    } else {
+      if (a.n > 32) hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, false, 1, true>), fgd, fbd, 0, stream, a);
+      else hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, false, 1, true>), fgd, fbd, 0, stream, a);
+    }
     return hipGetLastError();
   }
   if (a.mode == MODE_STEP && a.m > 64) {  // two constraint slots per lane (a box on every one of 64 variables is m = 128)

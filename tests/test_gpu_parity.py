@@ -619,7 +619,7 @@ def test_fused_vs_generic_random_shapes():
     tried = 0
     while tried < 40:
         level = rng.choice(["J", "QP"])
-        n = int(rng.integers(1, 33)) * 2 if level == "J" else int(rng.integers(2, 65))
+        n = int(rng.integers(2, 65))                          # any n; odd n with J-level input takes the flat-group stream
         k = int(rng.integers(0, min(15, n)))
         m = int(rng.integers(0, 65))
         m_r = int(rng.integers(1, 160))                       # any row count: a partial last 4-row group included
@@ -888,3 +888,49 @@ def test_tiny_batches_on_the_fused_kernels(batch):
     assert torch.all(out.status == 0) and torch.all(out.termination_state == Q.SATISFIED_KKT_TOL)
     G, c, half = Q.linearize(prob)
     np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", hb.J, hb.r), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,k,m,m_r", [(63, 8, 32, 128), (33, 4, 16, 64), (31, 3, 7, 33), (7, 2, 5, 9), (3, 0, 2, 3), (51, 14, 64, 101), (1 + 2 * 16, 0, 0, 4)])
+def test_fused_odd_n_with_stacked_jacobian(n, k, m, m_r):
+    """Odd n with (J, r, lambda) input: rows of J are only 8-byte aligned, so the 4-row groups go through the ring as flat runs
+    (dword DMA) and the operands are picked out with masked 8-byte LDS reads.  Step, Iterate and Solve against the oracle / the
+    generic kernel; m_r odd makes the per-problem base of J and r 8-byte aligned only."""
+    rng = np.random.default_rng(n * 11 + m_r)
+    B = 10
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k)); b = 0.2 * rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32)
+    ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n))
+    sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    mu = np.full(B, 0.05)
+    lam = 0.3 if m_r < n else 1e-3
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
+                       cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca) if m else None, cons_b=T(cb) if m else None)
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused_mfma"), s.step_kernel()
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, J=J, r=r, lam=lam, A_eq=A if k else None, b_eq=b if k else None,
+                                                            cons_var=cv if m else None, cons_a=ca if m else None, cons_b=cb if m else None,
+                                                            vars_=vars_, mu=mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-9
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12, barrier_strategy=Q.PREDICTOR_CORRECTOR,
+              initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+    res = {}
+    for force in (False, True):
+        sv = Q.QPInteriorPointSolver(prob, force_generic=force)
+        sv.SetVariables(T(vars_))
+        ip, st = sv.Iterate(T(mu), Q.COMPLEMENTARITY)
+        assert torch.all(st == 0)
+        after = sv.variables().cpu().numpy().copy()
+        out = sv.Solve(Q.Params(**kw))
+        assert torch.all(out.status == 0)
+        res[force] = (after, sv.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
+    np.testing.assert_allclose(res[False][0], res[True][0], rtol=1e-8, atol=1e-10)
+    same = (res[False][2] == res[True][2]) & (res[False][3] == res[True][3]) & (res[False][3] == Q.SATISFIED_KKT_TOL)
+    assert same.mean() >= 0.7, (res[False][2], res[True][2], res[False][3])
+    np.testing.assert_allclose(res[False][1][same][:, :n], res[True][1][same][:, :n], rtol=1e-6, atol=1e-8)
