@@ -622,7 +622,7 @@ __device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
-// NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 14, m <= 64, m_r % 4 == 0 are
+// NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 15 (index 15 of the y tile carries the right-hand side), m <= 64 MC are
 // checked by fused_supported().
 // MC = constraint slots per lane (m <= 64 MC).
 template <int NT, int WPS, int MC = 1> struct FusedCfg {
@@ -1571,7 +1571,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   }
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
-  if (a.k > 14 || a.m < 0) return false;
+  if (a.k > 15 || a.m < 0) return false;
   // two constraint slots per lane (m <= 128): the step kernel on every tile grid, Solve / Iterate on the 32 / 64 grids
   if (a.m > ((a.mode == MODE_STEP || a.n <= 64) ? 128 : 64)) return false;
   if (!a.ticket || !a.vars) return false;

@@ -386,10 +386,10 @@ def test_fused_solve_vs_oracle(cfg, guess, strategy):
 
 
 # ------------------------------------------------------------------ fused-kernel edge cases (shapes it accepts beyond the BASELINE configs)
-@pytest.mark.parametrize("n,k,m,m_r", [(32, 0, 0, 8), (32, 0, 10, 36), (32, 14, 2, 64), (64, 0, 64, 4), (64, 14, 0, 132), (64, 1, 1, 128),
+@pytest.mark.parametrize("n,k,m,m_r", [(32, 0, 0, 8), (32, 0, 10, 36), (32, 15, 2, 64), (64, 0, 64, 4), (64, 15, 0, 132), (64, 1, 1, 128),
                                        (64, 3, 9, 1), (64, 8, 32, 131), (32, 4, 16, 66), (32, 0, 5, 3)])
 def test_fused_edge_shapes(n, k, m, m_r):
-    """k = 0, m = 0, k = 14 (the largest the right-hand-side column leaves room for), m = 64, tiny and ragged m_r, duplicated
+    """k = 0, m = 0, k = 15 (the largest the right-hand-side column leaves room for), m = 64, tiny and ragged m_r, duplicated
     constraint variables -- all through the fused kernel, against the oracle."""
     rng = np.random.default_rng(n * 1000 + k * 100 + m + m_r)
     B = 33
@@ -620,7 +620,7 @@ def test_fused_vs_generic_random_shapes():
     while tried < 40:
         level = rng.choice(["J", "QP"])
         n = int(rng.integers(2, 65))                          # any n; odd n with J-level input takes the flat-group stream
-        k = int(rng.integers(0, min(15, n)))
+        k = int(rng.integers(0, min(16, n)))                  # up to 15 equalities
         m = int(rng.integers(0, 65))
         m_r = int(rng.integers(1, 160))                       # any row count: a partial last 4-row group included
         V = n + 2 * m + k
