@@ -1,26 +1,27 @@
-// kkt_fused.hip -- fused single-wavefront Newton-step kernel for gfx950 (MI355X), fp64, n = 32 or 64.
+// kkt_fused.hip -- fused single-wavefront KKT kernels for gfx950 (MI355X), fp64: Newton step, Iterate / Solve, linearisation.
 //
-// One 64-lane wavefront (= one workgroup) owns one QP at a time and keeps the WHOLE reduced KKT matrix in registers
-// as 16x16 tiles in the v_mfma_f64_16x16x4_f64 C/D fragment layout (lane (g = l>>4, j = l&15), register t holds
-// element (row g + 4t, column j)).  Nothing but a few small vectors ever touches LDS.
+// One 64-lane wavefront owns one QP at a time and keeps the WHOLE reduced KKT matrix in registers as 16x16 tiles in the
+// v_mfma_f64_16x16x4_f64 C/D fragment layout (lane (g = l>>4, j = l&15), register t holds element (row g + 4t, column j)).
+// Shapes: any n <= 128 (padded inside the kernel to a 32 / 64 / 96 / 128 tile grid), k <= 15, m <= 128; see fused_supported().
 //
-//   P1  J (m_r x n, row-major) is streamed from HBM exactly once with 16-byte loads straight into MFMA operand
-//       registers (no LDS staging): G = J^T J is accumulated on the matrix cores as the upper block triangle of tiles,
-//       c = J^T r on the VALU.  A lane's 16-byte load holds two adjacent columns, which induces a fixed permutation of
-//       the variables (position 16c + i  <->  column 32(c>>1) + 2i + (c&1)); the KKT system is solved in that order.
-//       [residual.hpp:206-224, nonlinear.cc:182-189]
+//   P0  The small per-problem vectors (x, s, z, y, b_eq, constraints) go global -> LDS by dword DMA, behind the ring fill.
+//   P1  J (m_r x n, row-major) is streamed from HBM exactly once through a per-wave LDS-DMA ring straight into MFMA operand
+//       registers: G = J^T J is accumulated on the matrix cores as the upper block triangle of tiles, c = J^T r on the VALU.
+//       A lane's 16-byte piece holds two adjacent columns, which induces a fixed permutation of the variables
+//       (position 16c + i  <->  column 32(c>>1) + 2i + (c&1)); the KKT system is solved in that order.  QP-level input loads the
+//       tiles from G instead (identity order).                                     [residual.hpp:206-224, nonlinear.cc:182-189]
 //   P2-4 lambda and the barrier diagonal Sigma (qp.cc:293-298) go onto the diagonal tiles; A_eq^T and the right-hand
-//       side form one more tile column [A_eq^T | rhs].
+//       side form one more tile column [A_eq^T | rhs] (the rhs in column 15).
 //   P5  Block LDL^T with 16x16 pivot blocks: each diagonal tile is inverted in registers by a symmetric sweep (wave
 //       broadcasts only), the panel Z = T^-1 U and the trailing update U_bc -= U_ab^T Z_c run on the matrix cores.
 //       Because the right-hand side rides along as a tile column, the forward substitution is free.  [qp.cc:302]
 //   P6  Backward substitution on the VALU, arranged so that no fragment-layout conversion is needed.
-//   P7  ds, dz (qp.cc:359-363), alpha (qp.cc:485-507), status, coalesced 16-byte stores of delta.
+//   P7  ds, dz (qp.cc:359-363), alpha (qp.cc:485-507), status, stores of delta.
 //
-// The system is solved for the NEW iterate (x+, -y+): [G+Sigma, A^T; A, 0] [x+; -y+] = [rhs_x; -b_eq] with
+// The step kernel solves for the NEW iterate (x+, -y+): [G+Sigma, A^T; A, 0] [x+; -y+] = [rhs_x; -b_eq] with
 // rhs_x[v] = -c[v] + sum_{i on v} a_i (z_i (s_i - b_i) + mu) / s_i, which is the reference's reduced system
 // (qp.cc:255-268) with K [x; -y] added to both sides: identical direction delta = (x+ - x, ds, y+ - y, dz) without the
-// G x, A x and A^T y products of EvaluateKKTConditions (qp.cc:404-408).
+// G x, A x and A^T y products of EvaluateKKTConditions (qp.cc:404-408).  The Solve kernel keeps the reference's residual form.
 //
 // Roofline: per problem 73.6 KB of algorithmic HBM traffic and 440 f64 MFMAs (320 for J^T J at n = 64); see DESIGN.md.
 #include <math.h>
