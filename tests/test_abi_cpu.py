@@ -70,3 +70,37 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle" not in txt.lower() or f in (), (dirpath, f)
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """sizeof / offsetof of every struct of include/mini_opt_hip.h, as gcc sees them, against the ctypes mirrors in
+    mini_opt_amd/_lib.py (a silent mismatch would shift every pointer that follows)."""
+    import ctypes
+    import subprocess
+    from mini_opt_amd import _lib as L
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = tmp_path / "abi.c"
+    checks = {
+        "mo_plan_desc": (L.PlanDesc, ["n", "m_r", "flags", "max_batch"]),
+        "mo_problem": (L.Problem, ["J", "r", "lambda", "G", "c", "A_eq", "b_eq", "cons_var", "cons_stride", "lambda_vec", "lambda_stride"]),
+        "mo_solve_params": (L.SolveParams, ["initial_mu", "max_iterations", "initial_guess_method", "initialize_mu_with_complementarity"]),
+        "mo_nls_params": (L.NlsParams, ["max_iterations", "termination_kkt_tolerance", "max_line_search_iterations", "armijo_search_tau",
+                                        "lambda_initial", "min_lambda"]),
+        "mo_nls_problem": (L.NlsProblem, ["vars", "candidate", "J", "J_ld", "r", "J_eq", "J_eq_ld", "r_eq", "r_cand", "r_eq_cand", "cons_var",
+                                          "cons_stride"]),
+    }
+    rename = {"lambda": "lam"}  # python keyword
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mini_opt_hip.h"', "int main(void) {"]
+    for cname, (_, fields) in checks.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, (cls, fields) in checks.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for f in fields:
+            assert int(out[f"{cname}.{f}"]) == getattr(cls, rename.get(f, f)).offset, (cname, f)
