@@ -348,3 +348,26 @@ def test_fp32_variants_of_the_support_entry_points():
     from mini_opt_amd import _lib as L
     with pytest.raises(L.MiniOptError):
         NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, P.rosenbrock_torch, cost_rows=2), batch=2, dtype=torch.float32)
+
+
+def test_nls_isolates_a_failing_problem_and_handles_degenerate_calls():
+    """A NaN start makes that problem's QP fail (the reference would throw out of Solve): it ends with QP_FAILURE and its QP status, the
+    neighbours are untouched.  max_iterations = 0 returns MAX_ITERATIONS without calling the residuals."""
+    guesses = np.array(P.ROSENBROCK_GUESSES, dtype=float)
+    guesses[3] = [np.nan, 1.0]
+    calls = {"n": 0}
+
+    def cost(x, want_J):
+        calls["n"] += 1
+        return P.rosenbrock_torch(x, want_J)
+
+    nls = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, cost, cost_rows=2, inequality_constraints=[(0, 1.0, 50.0)]), batch=len(guesses))
+    out = nls.Solve(NLS.Params(max_iterations=8, max_qp_iterations=10), T(guesses))
+    term = out.termination_state.cpu().numpy(); st = out.status.cpu().numpy()
+    assert term[3] == NLS.QP_FAILURE and st[3] != 0
+    good = [i for i in range(len(guesses)) if i != 3]
+    assert np.all(st[good] == 0) and np.all(np.isin(term[good], [NLS.SATISFIED_ABSOLUTE_TOL, NLS.SATISFIED_RELATIVE_TOL, NLS.SATISFIED_FIRST_ORDER_TOL]))
+    np.testing.assert_allclose(nls.variables().cpu().numpy()[good], 1.0, atol=1e-5)
+    calls["n"] = 0
+    out0 = nls.Solve(NLS.Params(max_iterations=0), T(np.array(P.ROSENBROCK_GUESSES, dtype=float)))
+    assert calls["n"] == 0 and torch.all(out0.termination_state == NLS.MAX_ITERATIONS) and torch.all(out0.num_iterations == 0)
