@@ -161,8 +161,12 @@ def main():
                                "algorithmic_flops_per_step": synth.algorithmic_flops(n, k, m, m_r), "kernel_ms": kernel_ms,
                                "hbm_gbs_algorithmic": achieved}
 
-        # parity gate on a sample (oracle = checker only)
+        # The cpu_baseline leg (rank 0 at N = 1 only; --no-cpu-baseline skips it entirely, e.g. under rocprofv3): the ONLY place where
+        # bench.py touches oracle/ -- once as the checker of a sample of the launch just timed, once as the timed CPU baseline.
+        out["parity"] = None
         try:
+            if info.world_size > 1 or args.no_cpu_baseline:
+                raise StopIteration
             from oracle import oracle as orc
             ns = min(args.parity_sample, batch)
             sl = slice(0, ns)
@@ -175,7 +179,7 @@ def main():
             err = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
             out["parity"] = {"sample": ns, "max_rel_inf": float(err.max()), "tolerance": 1e-10 if T == 8 else 2e-3,
                              "passed": bool(err.max() < (1e-10 if T == 8 else 2e-3))}
-            if info.world_size == 1 and not args.no_cpu_baseline:
+            if True:
                 cores = usable_cores()
                 pilot = min(batch, 4 * cores)
                 hs = lambda t, cnt: t[:cnt].double().cpu().numpy()
@@ -201,6 +205,8 @@ def main():
                     "value": cnt / float(np.median(reps)), "unit": "steps/s", "cores": used, "kind": "port",
                     "sample": f"first {cnt} problems of the same batch, {len(reps)} repeats (median), OpenMP over problems; "
                               "plain-C restatement of the reference step incl. its explicit inverse (qp.cc:310-311); Eigen itself is absent from the image"}
+        except StopIteration:
+            pass
         except Exception as exc:  # the oracle is only the checker; never let it hide the measurement
             out["parity"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)

@@ -72,6 +72,20 @@ def test_product_never_imports_oracle():
                     assert "oracle" not in txt.lower() or f in (), (dirpath, f)
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_leg_touch_the_oracle():
+    """tools/ never imports the oracle; bench.py does so only inside its cpu_baseline leg (skipped by --no-cpu-baseline and at N > 1)."""
+    import re
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh", ".hip")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"(from|import)\s+oracle", txt), (dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(re.findall(r"(?:from|import)\s+oracle", bench)) == 1
+    guard = bench.index("if info.world_size > 1 or args.no_cpu_baseline:")
+    assert guard < bench.index("from oracle import oracle")
+
+
 def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     """sizeof / offsetof of every struct of include/mini_opt_hip.h, as gcc sees them, against the ctypes mirrors in
     mini_opt_amd/_lib.py (a silent mismatch would shift every pointer that follows)."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Secondary measurement: the batched SQP loop (mo_nls_solve) on a many-start Himmelblau sweep (nonlinear_test.cc:597-664
-scaled up), with the oracle's single-problem loop timed beside it on a sample.  usage: python tools/bench_nls.py [starts]"""
+scaled up).  usage: python tools/bench_nls.py [starts]"""
 import json
 import os
 import sys
@@ -38,16 +38,6 @@ def main():
            "satisfied_frac": float(NLS.TerminationStateIndicatesSatisfiedTol(out.termination_state).double().mean()),
            "at_an_optimum_frac": float((dist < 5e-5).mean()), "mean_outer_iterations": float(out.num_iterations.double().mean()),
            "mean_qp_iterations": float(out.NumQPIterations().double().mean())}
-    try:
-        from oracle import nls_oracle as N
-        ref = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.himmelblau_np, inequality_constraints=cons))
-        ns = min(B, 256)
-        t = time.perf_counter()
-        for gi in guesses[:ns]:
-            ref.solve(N.Params(**kw), gi)
-        res["oracle_problems_per_s_1core"] = ns / (time.perf_counter() - t)
-    except Exception as e:  # the oracle is optional here
-        res["oracle_error"] = str(e)
     print(json.dumps(res), flush=True)
 
 
