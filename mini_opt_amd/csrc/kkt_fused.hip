@@ -1198,13 +1198,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
 
     double n_rd2 = 0, n_rpe2 = 0, n_rc2 = 0, n_rc1 = 0, n_rpi2 = 0;
-    auto kkt_errors = [&](double mu_e, double (&o)[4]) {  // ComputeErrors, qp.cc:423-437
-      o[0] = sqrt(n_rd2);
-      o[2] = k > 0 ? sqrt(n_rpe2) : 0.0;
+    // ComputeErrors (qp.cc:423-437) as SQUARED norms: the decisions compare squares (all quantities are non-negative); the four f64
+    // square roots per call (~120 VALU instructions) are only taken for the iteration records, i.e. when the caller asked for them.
+    auto kkt_errors_sq = [&](double mu_e, double (&o)[4]) {
+      o[0] = n_rd2;
+      o[2] = k > 0 ? n_rpe2 : 0.0;
       if (m > 0) {
         const double corrected = n_rc2 - 2 * (n_rc1 * mu_e) + (mu_e * mu_e) * (double)m;
-        o[1] = sqrt(corrected > 0.0 ? corrected : 0.0);
-        o[3] = sqrt(n_rpi2);
+        o[1] = corrected > 0.0 ? corrected : 0.0;
+        o[3] = n_rpi2;
       } else { o[1] = 0.0; o[3] = 0.0; }
     };
     // G = J^T J + lambda I and c = J^T r do not change between the passes of one Solve: the first pass parks its tiles in a per-problem
@@ -1360,31 +1362,37 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         // ---- the decision point of Solve (qp.cc:116-147)
         if (it > 0) {
           double kf[4];
-          kkt_errors(mu_used, kf);                                  // kkt_after of the previous iteration, qp.cc:127
+          kkt_errors_sq(mu_used, kf);                               // kkt_after of the previous iteration (squared), qp.cc:127
           const double cur_mu = m > 0 ? n_rc1 / (double)m : 0.0;    // ComputeMu, qp.cc:509-516
-          if (iter_out && lane == 0) {
-            double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
-            rec[4] = kf[0]; rec[5] = kf[1]; rec[6] = kf[2]; rec[7] = kf[3];
-            rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
-            rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
+          if (iter_out) {                                           // wave-uniform
+            const double r4 = sqrt(kf[0]), r5 = sqrt(kf[1]), r6 = sqrt(kf[2]), r7 = sqrt(kf[3]);
+            if (lane == 0) {
+              double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
+              rec[4] = r4; rec[5] = r5; rec[6] = r6; rec[7] = r7;
+              rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
+              rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
+            }
           }
-          double kmax = kf[0];
-          kmax = kf[1] > kmax ? kf[1] : kmax; kmax = kf[2] > kmax ? kf[2] : kmax; kmax = kf[3] > kmax ? kf[3] : kmax;
-          if (kmax < sp.termination_kkt_tol && cur_mu < sp.termination_complementarity_tol) {  // qp.cc:132-137
+          double kmax2 = kf[0];                                     // KKTError::Max() squared
+          kmax2 = kf[1] > kmax2 ? kf[1] : kmax2; kmax2 = kf[2] > kmax2 ? kf[2] : kmax2; kmax2 = kf[3] > kmax2 ? kf[3] : kmax2;
+          if (kmax2 < sp.termination_kkt_tol * sp.termination_kkt_tol && cur_mu < sp.termination_complementarity_tol) {  // qp.cc:132-137
             term = MO_SATISFIED_KKT_TOL;
             break;
           }
-          if (kmax <= mu || !sp.decrease_mu_only_on_small_error) {                             // qp.cc:140-146
+          if (kmax2 <= mu * mu || !sp.decrease_mu_only_on_small_error) {                       // qp.cc:140-146 (mu > 0)
             if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= sp.sigma;
             else mu = sp.sigma * cur_mu;
           }
         }
         if (it >= sp.max_iterations) break;                          // MAX_ITERATIONS, qp.cc:149
-        double ki[4];
-        kkt_errors(mu, ki);                                          // kkt_prev, qp.cc:118
-        if (iter_out && lane == 0) {
-          double* rec = iter_out + (size_t)it * MO_ITER_RECORD;
-          rec[0] = ki[0]; rec[1] = ki[1]; rec[2] = ki[2]; rec[3] = ki[3];
+        if (iter_out) {                                              // kkt_prev is only ever recorded, qp.cc:118
+          double ki[4];
+          kkt_errors_sq(mu, ki);
+          const double r0 = sqrt(ki[0]), r1 = sqrt(ki[1]), r2 = sqrt(ki[2]), r3 = sqrt(ki[3]);
+          if (lane == 0) {
+            double* rec = iter_out + (size_t)it * MO_ITER_RECORD;
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
+          }
         }
       }
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction

@@ -272,14 +272,16 @@ class QPInteriorPointSolver:
         return ip, self.status_
 
     # -- Solve, qp.cc:100-151 ----------------------------------------------------------------------------------
-    def Solve(self, params: Params) -> SolverOutputs:
+    def Solve(self, params: Params, record_iterations: bool = True) -> SolverOutputs:
+        """qp.cc:100-151.  record_iterations=False skips the per-iteration QPInteriorPointIteration records (outputs.iterations is None):
+        the kernel then never takes the square roots of the KKT norms."""
         if self.p_ is None:
             raise L.MiniOptError(-1, "Must have a valid problem")
         dev, dt = self.variables_.device, self.p_.dtype
         term = torch.zeros(self.batch, dtype=torch.int32, device=dev)
         nit = torch.zeros(self.batch, dtype=torch.int32, device=dev)
         its = torch.full((self.batch, max(int(params.max_iterations), 1), L.MO_ITER_RECORD), float("nan"), dtype=dt,
-                         device=dev)
+                         device=dev) if record_iterations else None
         lag = torch.zeros(self.batch, 2, dtype=dt, device=dev) if self.p_.k > 0 else None
         sp = params.as_struct()
         L.check(L.lib().mo_qp_solve(self._plan, C.byref(self._prob), self.batch, C.byref(sp), _ptr(self.variables_),

@@ -45,6 +45,8 @@ def main():
             t = timeit(run, 2)
             o = res["o"]
             out["solve%s_per_s" % sname] = batch / t
+            t2 = timeit(lambda: s.Solve(params, record_iterations=False), 2)
+            out["solve%s_no_records_per_s" % sname] = batch / t2
             out["solve%s_mean_iterations" % sname] = float(o.num_iterations.double().mean())
             out["solve%s_satisfied_frac" % sname] = float((o.termination_state == 0).double().mean())
             out["solve%s_status_ok_frac" % sname] = float((o.status == 0).double().mean())
