@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
   const int k = a.k, m = a.m, m_r = a.m_r;
   const int nn = a.n;  // actual number of variables <= N (see the step kernel)
+  const double inv_m = m > 0 ? 1.0 / (double)m : 0.0;
   const mo_solve_params& sp = a.sp;
   for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
   lds_fence();
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       if (sp.initialize_mu_with_complementarity) {  // qp.cc:115
         const double t = wave_sum_f64(sz);
-        mu = m > 0 ? t / (double)m : 0.0;
+        mu = t * inv_m;
       }
     };
     if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
@@ -1363,7 +1364,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         if (it > 0) {
           double kf[4];
           kkt_errors_sq(mu_used, kf);                               // kkt_after of the previous iteration (squared), qp.cc:127
-          const double cur_mu = m > 0 ? n_rc1 / (double)m : 0.0;    // ComputeMu, qp.cc:509-516
+          const double cur_mu = n_rc1 * inv_m;                      // ComputeMu, qp.cc:509-516 (one f64 division per kernel, not per pass)
           if (iter_out) {                                           // wave-uniform
             const double r4 = sqrt(kf[0]), r5 = sqrt(kf[1]), r6 = sqrt(kf[2]), r7 = sqrt(kf[3]);
             if (lane == 0) {
@@ -1502,11 +1503,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
         const double sdz = wave_sum_f64(t_sdz), zds = wave_sum_f64(t_zds), dsdz = wave_sum_f64(t_dsdz);
         double ma = mu;                                                                // qp.cc:519-537
-        ma += ad * sdz / (double)m;
-        ma += ap * zds / (double)m;
-        ma += (ad * ap) * dsdz / (double)m;
+        ma += ad * sdz * inv_m;
+        ma += ap * zds * inv_m;
+        ma += (ad * ap) * dsdz * inv_m;
         mu_aff = ma > 0.0 ? ma : 0.0;
-        const double ratio = mu_aff / mu;
+        const double ratio = mu_aff * rcp_f64(mu);
         mu_pc = (ratio * ratio * ratio) * mu;                                          // qp.cc:182-183
         corrector_pass = true;
         lds_fence();
