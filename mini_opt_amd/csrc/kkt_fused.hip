@@ -1241,15 +1241,18 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
       load_a_tiles<NT, QPL>(Ap, a.A_ld, k, nn, g, j, U);
+      // The corrector pass of Mehrotra's scheme works on the state the predictor pass just saw: its residual (parked in LDS) is reused
+      // instead of redoing the tile products and norms.
+      const bool reuse_residual = corrector_pass;  // wave-uniform
       // publish the state for the layout conversions below; zero the per-variable scatter arrays
-      if (g == 0) {
+      if (g == 0 && !reuse_residual) {
         stv<NT, QPL>(xs, j, xv);
 #pragma unroll
         for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
         ysm[j] = (j < k) ? yv : 0.0;
       }
       if (lane < N / 2) {
-        azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0;
+        if (!reuse_residual) { azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0; }  // azS keeps r_d for the corrector pass
         diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
         rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0;
       }
@@ -1304,11 +1307,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       for (int ci = 0; ci < MC; ++ci) {
         r_pi[ci] = 0.0; r_comp[ci] = 0.0;
         if (include_ineq && lane + 64 * ci < m) {
-          atomicAdd(&azS[cvar[ci]], ca[ci] * cz[ci]);                    // qp.cc:415
+          if (!reuse_residual) atomicAdd(&azS[cvar[ci]], ca[ci] * cz[ci]);  // qp.cc:415
           r_pi[ci] = ca[ci] * xs[cvar[ci]] + cb[ci] - cs[ci];            // qp.cc:416
           r_comp[ci] = cs[ci] * cz[ci];                                  // qp.cc:417
         }
       }
+      double r_d[NT], r_pe;
+      if (reuse_residual) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) r_d[c] = azS[16 * c + j];
+        r_pe = (j < k) ? -ysm[16 + j] : 0.0;  // part B of the predictor pass left -r_pe there
+      } else {
       // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
       // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
       double acc1[NB];
@@ -1337,14 +1346,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       lds_fence();
-      double r_d[NT];
       {
         double azv[NT];
         ldv<NT, QPL>(azS, j, azv);
 #pragma unroll
         for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
       }
-      const double r_pe = (j < k) ? cross_row_sum(acc1[NT]) + b_col : 0.0;                                 // qp.cc:408
+      r_pe = (j < k) ? cross_row_sum(acc1[NT]) + b_col : 0.0;                                              // qp.cc:408
+      if (use_pc && g == 0) {  // park r_d for the corrector pass (azS has been consumed)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) azS[16 * c + j] = r_d[c];
+      }
       {
         double t = 0.0;
 #pragma unroll
@@ -1358,6 +1370,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         n_rc1 = wave_sum_f64(s_rc1);
         n_rpi2 = wave_sum_f64(s_rpi2);
         n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
+      }
       }
       if (!guess_pass && !iterate_mode && !corrector_pass) {
         // ---- the decision point of Solve (qp.cc:116-147)
