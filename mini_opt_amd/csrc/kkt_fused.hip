@@ -622,6 +622,62 @@ __device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k
   }
 }
 
+// A SECOND right-hand side through the factors block_eliminate left in the tiles (diagonal tiles: -T^-1, row panels: their
+// forward-eliminated values) -- what Mehrotra's corrector needs: same matrix, new rhs.  Vectors are V16 (value at lane j, replicated
+// over g); the row-layout copies a tile product needs go through a 16-double LDS hop.  rb[] is consumed; the forward-eliminated
+// blocks are parked in rbuf_x / rbuf_y for the substitution.  xb[c] = solution at permuted position 16c + j, xb[NT] = the y block.
+template <int NT>
+__device__ inline void solve_second_rhs(const d4 (&U)[(NT + 1) * (NT + 1)], int k, int g, int j, double (&rb)[NT + 1], double* hop,
+                                        double* rbuf_x, double* rbuf_y, double (&xb)[NT + 1]) {
+  constexpr int NB = NT + 1;
+  rb[NT] = (j < k) ? rb[NT] : 0.0;  // lanes beyond the k equalities carry the first solve's leftovers in the tiles: keep them out
+#pragma unroll
+  for (int pa = 0; pa < NB; ++pa) {  // forward: r_b += U_ab^T (-T_a^-1 r_a), b > a
+    if (pa == NT) rb[NT] = (j < k) ? rb[NT] : 0.0;
+    if (g == 0) { hop[j] = rb[pa]; (pa < NT ? rbuf_x + 16 * pa : rbuf_y)[j] = rb[pa]; }
+    lds_fence();
+    if (pa < NT) {
+      double q = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], hop[g + 4 * t], q);
+      const double w = cross_row_sum(q);  // (-T_a^-1 r_a)(j)
+      lds_fence();                        // hop has been read
+      if (g == 0) hop[j] = w;
+      lds_fence();
+      double wr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wr[t] = hop[g + 4 * t];
+#pragma unroll
+      for (int pb = pa + 1; pb < NB; ++pb) {
+        double q2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q2 = fma(U[pa * NB + pb][t], wr[t], q2);
+        rb[pb] += cross_row_sum(q2);
+      }
+      lds_fence();                        // hop has been read before the next block overwrites it
+    }
+  }
+#pragma unroll
+  for (int pa = NT; pa >= 0; --pa) {  // backward, as back_substitute() but with the rhs read from LDS
+    const double* rsrc = pa < NT ? rbuf_x + 16 * pa : rbuf_y;
+    double vt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double pt = 0.0;
+#pragma unroll
+      for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
+      if (pa < NT) pt = row_sum(pt);
+      vt[t] = rsrc[g + 4 * t] - pt;
+    }
+    double q = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);
+    xb[pa] = -cross_row_sum(q);
+    if (pa == NT) xb[NT] = (j < k) ? xb[NT] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- the kernel ------------------------------------------------------------------------------------------------
 // NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 15 (index 15 of the y tile carries the right-hand side), m <= 64 MC are
 // checked by fused_supported().
@@ -1036,13 +1092,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
 // [G x + c - A^T y - A_i^T z ; A x + b] as a tile product K [x; -y] in registers (qp.cc:404-419), and -- unlike the
 // one-shot step kernel -- solves for the DIRECTION with the residual as right-hand side, exactly the reference's system
 // (qp.cc:255-268, 337-363), so the loop keeps Newton's self-correcting behaviour down to tight KKT tolerances.
-// All three BarrierStrategy values; PREDICTOR_CORRECTOR costs two passes (two factorisations) per iteration.
+// All three BarrierStrategy values; PREDICTOR_CORRECTOR pushes its second right-hand side through the first solve's factors.
 template <int NT, int WPS, int MC = 1> struct SolveCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;
   static constexpr int SLOT = NH * 1024 + 64;
   static constexpr int MCAP = 64 * MC;                    // constraint slots: MC per lane
-  static constexpr int VEC = (6 * N + 32 + 2 * MCAP) * 8;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32], affine ds / dz [2][MCAP]
+  static constexpr int VEC = (6 * N + 32) * 8;            // xs, xp, azS, diagS, rhoS, tmp, ysmall[32]
   static constexpr int D_FIT = ((160 * 1024) / (4 * WPS) - VEC) / SLOT;
   static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
   static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);
@@ -1055,7 +1111,6 @@ __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v
 template <int NT, int WPS, int SW, bool QPL, int MC = 1, bool FLAT = false>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
   using C = SolveCfg<NT, WPS, MC>;
-  constexpr int MCAP = C::MCAP;
   constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
 
@@ -1069,7 +1124,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   double* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
   double* const tmp = rhoS + N;                                   // layout-conversion scratch (R <-> V16, natural <-> permuted)
   double* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
-  double* const affS = ysm + 32;                                  // predictor-corrector: ds_aff [0,MCAP), dz_aff [MCAP,2 MCAP)
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
   const int k = a.k, m = a.m, m_r = a.m_r;
@@ -1218,11 +1272,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     bool tiles_cached = false;
     double mu_used = mu;   // the mu handed to the previous Iterate
     double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
-    // Mehrotra predictor-corrector (qp.cc:170-187): the predictor pass solves with mu = 0 and probes alpha(tau = 1); the
-    // corrector pass rebuilds and re-factors the same tiles (the elimination consumes them) with the second-order term
-    // ds_aff dz_aff and mu = sigma mu_input on the right-hand side.
+    // Mehrotra predictor-corrector (qp.cc:170-187): solve with mu = 0, probe alpha(tau = 1), then solve again with the second-order
+    // term ds_aff dz_aff and mu = sigma mu_input on the right-hand side -- through the factors of the first solve (solve_second_rhs).
     const bool use_pc = (iterate_mode ? a.barrier_strategy : sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
-    bool corrector_pass = false;
     double ip_mu = mu, probe_p = __builtin_nan(""), probe_d = __builtin_nan(""), mu_aff = __builtin_nan(""), mu_pc = 0.0;
 
     while (st == MO_STATUS_OK) {
@@ -1241,18 +1293,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
       load_a_tiles<NT, QPL>(Ap, a.A_ld, k, nn, g, j, U);
-      // The corrector pass of Mehrotra's scheme works on the state the predictor pass just saw: its residual (parked in LDS) is reused
-      // instead of redoing the tile products and norms.
-      const bool reuse_residual = corrector_pass;  // wave-uniform
       // publish the state for the layout conversions below; zero the per-variable scatter arrays
-      if (g == 0 && !reuse_residual) {
+      if (g == 0) {
         stv<NT, QPL>(xs, j, xv);
 #pragma unroll
         for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
         ysm[j] = (j < k) ? yv : 0.0;
       }
       if (lane < N / 2) {
-        if (!reuse_residual) { azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0; }  // azS keeps r_d for the corrector pass
+        azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0;
         diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
         rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0;
       }
@@ -1307,17 +1356,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       for (int ci = 0; ci < MC; ++ci) {
         r_pi[ci] = 0.0; r_comp[ci] = 0.0;
         if (include_ineq && lane + 64 * ci < m) {
-          if (!reuse_residual) atomicAdd(&azS[cvar[ci]], ca[ci] * cz[ci]);  // qp.cc:415
+          atomicAdd(&azS[cvar[ci]], ca[ci] * cz[ci]);                    // qp.cc:415
           r_pi[ci] = ca[ci] * xs[cvar[ci]] + cb[ci] - cs[ci];            // qp.cc:416
           r_comp[ci] = cs[ci] * cz[ci];                                  // qp.cc:417
         }
       }
       double r_d[NT], r_pe;
-      if (reuse_residual) {
-#pragma unroll
-        for (int c = 0; c < NT; ++c) r_d[c] = azS[16 * c + j];
-        r_pe = (j < k) ? -ysm[16 + j] : 0.0;  // part B of the predictor pass left -r_pe there
-      } else {
+      {
       // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
       // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
       double acc1[NB];
@@ -1353,10 +1398,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
       }
       r_pe = (j < k) ? cross_row_sum(acc1[NT]) + b_col : 0.0;                                              // qp.cc:408
-      if (use_pc && g == 0) {  // park r_d for the corrector pass (azS has been consumed)
-#pragma unroll
-        for (int c = 0; c < NT; ++c) azS[16 * c + j] = r_d[c];
-      }
       {
         double t = 0.0;
 #pragma unroll
@@ -1372,7 +1413,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
       }
       }
-      if (!guess_pass && !iterate_mode && !corrector_pass) {
+      if (!guess_pass && !iterate_mode) {
         // ---- the decision point of Solve (qp.cc:116-147)
         if (it > 0) {
           double kf[4];
@@ -1410,13 +1451,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
-      const bool predictor_pass = use_pc && !guess_pass && !corrector_pass;
-      const double mu_step = m > 0 ? (predictor_pass ? 0.0 : (corrector_pass ? mu_pc : mu)) : 0.0;  // qp.cc:165-187
+      const bool predictor_pass = use_pc && !guess_pass;  // Mehrotra: solve with mu = 0, probe, then the corrector through the same factors
+      const double mu_step = m > 0 ? (predictor_pass ? 0.0 : mu) : 0.0;  // qp.cc:165-187
       double aff[MC], cs_inv[MC];
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci) {
-        const int ix = lane + 64 * ci;
-        aff[ci] = (corrector_pass && ix < m) ? affS[ix] * affS[MCAP + ix] : 0.0;                  // ds_aff dz_aff, qp.cc:341
+        aff[ci] = 0.0;  // ds_aff dz_aff (qp.cc:341), set by the predictor
         cs_inv[ci] = 1.0;
       }
       if (include_ineq) {
@@ -1467,52 +1507,60 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       if (!block_eliminate<NT, SW>(U, k, g, j)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
       double xb[NB];
       back_substitute<NT>(U, k, j, xb);      // xb[c] = dx (permuted), xb[NT] = -dy
-      const double dyv = (j < k) ? -xb[NT] : 0.0;
-      bool finite = fabs(dyv) < INFINITY;
+      double dyv = 0.0, dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
+      // From a solution xb to the direction: dy, dx (natural order in LDS), ds, dz, the step lengths (qp.cc:359-363, 485-507).
+      auto finish_direction = [&](double mu_s, double tau) -> bool {
+        dyv = (j < k) ? -xb[NT] : 0.0;
+        bool finite = fabs(dyv) < INFINITY;
 #pragma unroll
-      for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
+        for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
+        if (g == 0) {
+          double dxn[NT];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) dxn[c] = xb[c];
+          stv<NT, QPL>(tmp, j, dxn);  // dx, natural order
+        }
+        lds_fence();
+        ap = 1.0; ad = 1.0;
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          dsv[ci] = 0.0; dzv[ci] = 0.0;
+          if (lane + 64 * ci < m) {
+            dsv[ci] = ca[ci] * tmp[cvar[ci]] + r_pi[ci];                                               // qp.cc:361
+            dzv[ci] = -(cz[ci] * cs_inv[ci]) * dsv[ci] - cs_inv[ci] * (r_comp[ci] + aff[ci] - mu_s);   // qp.cc:362
+            if (cs[ci] + dsv[ci] <= 0.0 && fabs(dsv[ci]) > 0.0) ap = fmin(ap, -tau * cs[ci] * rcp_f64(dsv[ci]));  // qp.cc:498-503
+            if (cz[ci] + dzv[ci] <= 0.0 && fabs(dzv[ci]) > 0.0) ad = fmin(ad, -tau * cz[ci] * rcp_f64(dzv[ci]));
+            finite = finite && (fabs(dsv[ci]) < INFINITY) && (fabs(dzv[ci]) < INFINITY);
+          }
+        }
+        if (!__all(finite)) return false;
+        ap = cross_row_min(row_min(ap));
+        ad = cross_row_min(row_min(ad));
+        return true;
+      };
       if (guess_pass) {                      // qp.cc:455-460: x, y <- the equality-constrained solution
+        bool finite = (j < k) ? (fabs(xb[NT]) < INFINITY) : true;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
         if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
 #pragma unroll
         for (int c = 0; c < NT; ++c) xv[c] = xb[c];
-        yv = dyv;
+        yv = (j < k) ? -xb[NT] : 0.0;
         guess_pass = false;
         clamp_and_init_slacks();
         continue;
       }
-      if (g == 0) {
-        double dxn[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) dxn[c] = xb[c];
-        stv<NT, QPL>(tmp, j, dxn);  // dx, natural order
-      }
-      lds_fence();
-      double dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
-#pragma unroll
-      for (int ci = 0; ci < MC; ++ci) {
-        dsv[ci] = 0.0; dzv[ci] = 0.0;
-        if (lane + 64 * ci < m) {
-          dsv[ci] = ca[ci] * tmp[cvar[ci]] + r_pi[ci];                                                 // qp.cc:361
-          dzv[ci] = -(cz[ci] * cs_inv[ci]) * dsv[ci] - cs_inv[ci] * (r_comp[ci] + aff[ci] - mu_step);  // qp.cc:362
-          const double tau = predictor_pass ? 1.0 : 0.995;                                             // qp.cc:174, 192
-          if (cs[ci] + dsv[ci] <= 0.0 && fabs(dsv[ci]) > 0.0) ap = fmin(ap, -tau * cs[ci] * rcp_f64(dsv[ci]));  // qp.cc:498-503
-          if (cz[ci] + dzv[ci] <= 0.0 && fabs(dzv[ci]) > 0.0) ad = fmin(ad, -tau * cz[ci] * rcp_f64(dzv[ci]));
-          finite = finite && (fabs(dsv[ci]) < INFINITY) && (fabs(dzv[ci]) < INFINITY);
-        }
-      }
-      if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
-      ap = cross_row_min(row_min(ap));
-      ad = cross_row_min(row_min(ad));
+      if (!finish_direction(mu_step, predictor_pass ? 1.0 : 0.995)) { st = MO_STATUS_NONFINITE; break; }  // tau: qp.cc:174, 192
+      ip_mu = mu;                                                                      // IPIterationOutputs::mu
       if (predictor_pass) {
         probe_p = ap; probe_d = ad;                                                    // alpha_probe, qp.cc:174
         double t_sdz = 0.0, t_zds = 0.0, t_dsdz = 0.0;
 #pragma unroll
         for (int ci = 0; ci < MC; ++ci) {
-          const int ix = lane + 64 * ci;
-          if (ix < m) {
-            affS[ix] = dsv[ci]; affS[MCAP + ix] = dzv[ci];                               // delta_affine_, qp.cc:177
+          if (lane + 64 * ci < m) {
             t_sdz = fma(cs[ci], dzv[ci], t_sdz); t_zds = fma(cz[ci], dsv[ci], t_zds); t_dsdz = fma(dsv[ci], dzv[ci], t_dsdz);
           }
+          aff[ci] = dsv[ci] * dzv[ci];                                                 // delta_affine_ (qp.cc:177) enters as ds_aff dz_aff
         }
         const double sdz = wave_sum_f64(t_sdz), zds = wave_sum_f64(t_zds), dsdz = wave_sum_f64(t_dsdz);
         double ma = mu;                                                                // qp.cc:519-537
@@ -1522,12 +1570,30 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         mu_aff = ma > 0.0 ? ma : 0.0;
         const double ratio = mu_aff * rcp_f64(mu);
         mu_pc = (ratio * ratio * ratio) * mu;                                          // qp.cc:182-183
-        corrector_pass = true;
+        // The corrector solve (qp.cc:187): same matrix, right-hand side with ds_aff dz_aff and sigma mu -- pushed through the factors
+        // still sitting in the tiles instead of a second factorisation.
+        if (lane < N / 2) { rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0; }
         lds_fence();
-        continue;
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          if (lane + 64 * ci < m) {
+            const double zs = cz[ci] * cs_inv[ci];
+            atomicAdd(&rhoS[cvar[ci]], ca[ci] * zs * r_pi[ci] + ca[ci] * (r_comp[ci] + aff[ci] - mu_pc) * cs_inv[ci]);  // qp.cc:340-341
+          }
+        }
+        lds_fence();
+        double rb[NB];
+        {
+          double rr[NT];
+          ldv<NT, QPL>(rhoS, j, rr);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) rb[c] = -(r_d[c] + rr[c]);
+          rb[NT] = (j < k) ? -r_pe : 0.0;
+        }
+        solve_second_rhs<NT>(U, k, g, j, rb, diagS, xp, ysm + 16, xb);
+        if (!finish_direction(mu_pc, 0.995)) { st = MO_STATUS_NONFINITE; break; }
+        ip_mu = mu_pc;
       }
-      ip_mu = corrector_pass ? mu_pc : mu;                                             // IPIterationOutputs::mu
-      corrector_pass = false;
       // x,s += alpha_p (dx,ds) ; y,z += alpha_d (dy,dz), qp.cc:196-199
 #pragma unroll
       for (int c = 0; c < NT; ++c) xv[c] = fma(xb[c], ap, xv[c]);
