@@ -1251,6 +1251,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
     };
     if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+    if (!iterate_mode && sp.initial_guess_method == MO_GUESS_USER_PROVIDED && sp.initialize_mu_with_complementarity) {
+      double sz = 0.0;  // qp.cc:115 on the caller's state: mu = s^T z / M (0 without inequalities, qp.cc:509-516)
+#pragma unroll
+      for (int ci = 0; ci < MC; ++ci)
+        if (lane + 64 * ci < m) sz = fma(cs[ci], cz[ci], sz);
+      mu = wave_sum_f64(sz) * inv_m;
+    }
 
     double n_rd2 = 0, n_rpe2 = 0, n_rc2 = 0, n_rc1 = 0, n_rpi2 = 0;
     // ComputeErrors (qp.cc:423-437) as SQUARED norms: the decisions compare squares (all quantities are non-negative); the four f64

@@ -91,17 +91,33 @@ int fill_problem(const mo_plan* plan, const mo_problem* prob, int64_t batch, boo
   return MO_OK;
 }
 
-int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
+// Which kernel serves a call is decided ONCE, here, from the plan flags, the process-wide MO_FORCE_GENERIC knob (read a single
+// time: the scratch a call prepares and the kernel that consumes it must come from the same decision) and the kernels' own
+// shape predicates.
+enum KernelChoice { KERNEL_FUSED_F64, KERNEL_FUSED_F32, KERNEL_GENERIC };
+
+bool generic_forced(const mo_plan* plan) {
+  static const bool env_force_generic = getenv("MO_FORCE_GENERIC") != nullptr;  // A/B and bisection knob
+  return env_force_generic || (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
+}
+
+KernelChoice choose_kernel(const mo_plan* plan, const mo::KernelArgs& a) {
+  if (!generic_forced(plan)) {
+    if (mo::fused_supported(a, plan->desc.dtype)) return KERNEL_FUSED_F64;
+    if (mo::fused_f32_supported(a, plan->desc.dtype)) return KERNEL_FUSED_F32;
+  }
+  return KERNEL_GENERIC;
+}
+
+int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice choice, void* stream) {
   if (a_in.batch == 0) return MO_OK;
   mo::KernelArgs a = a_in;
   a.ticket = plan->ticket;
   MO_HIP_CHECK(hipSetDevice(plan->desc.device));
   hipStream_t s = (hipStream_t)stream;
-  static const bool env_force_generic = getenv("MO_FORCE_GENERIC") != nullptr;  // A/B and bisection knob
-  const bool force_generic = env_force_generic || (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
-  if (!force_generic && mo::fused_supported(a, plan->desc.dtype)) {
+  if (choice == KERNEL_FUSED_F64) {
     MO_HIP_CHECK(mo::launch_fused(a, plan->desc.dtype, plan->num_cus, s));
-  } else if (!force_generic && mo::fused_f32_supported(a, plan->desc.dtype)) {
+  } else if (choice == KERNEL_FUSED_F32) {
     MO_HIP_CHECK(mo::launch_fused_f32(a, plan->num_cus, s));
   } else {
     const size_t need = mo::generic_lds_bytes(a, plan->elem);
@@ -111,6 +127,12 @@ int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
   return MO_OK;
+}
+
+int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
+  mo::KernelArgs a = a_in;
+  a.ticket = plan->ticket;
+  return launch_chosen(plan, a, choose_kernel(plan, a), stream);
 }
 
 }  // namespace
@@ -173,6 +195,7 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   if (desc->n <= 0 || desc->k < 0 || desc->m < 0 || desc->m_r < 0)
     return fail(MO_ERR_DIMENSION, "bad dimensions n=%d k=%d m=%d m_r=%d", desc->n, desc->k, desc->m, desc->m_r);
   if (desc->dtype != MO_F64 && desc->dtype != MO_F32) return fail(MO_ERR_UNSUPPORTED, "unknown dtype %d", desc->dtype);
+  if (desc->max_batch < 0) return fail(MO_ERR_INVALID_ARGUMENT, "max_batch must be >= 0 (got %lld)", (long long)desc->max_batch);
   if (desc->n + desc->k > 192) return fail(MO_ERR_UNSUPPORTED, "n + k = %d exceeds the LDS-resident limit of 192", desc->n + desc->k);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -228,9 +251,11 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned, densely packed state / output
   a.vars_stride = a.delta_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
   a.ticket = plan->ticket;
-  if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype)) return mo::fused_name(a, plan->desc.dtype);
-  if (!(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_f32_supported(a, plan->desc.dtype)) return mo::fused_f32_name(a);
-  return "generic";
+  switch (choose_kernel(plan, a)) {
+    case KERNEL_FUSED_F64: return mo::fused_name(a, plan->desc.dtype);
+    case KERNEL_FUSED_F32: return mo::fused_f32_name(a);
+    default: return "generic";
+  }
 }
 
 int mo_linearize(mo_plan* plan, const mo_problem* prob, int64_t batch, void* G_out, int64_t G_stride, int32_t G_ld,
@@ -410,14 +435,23 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
   a.status = status;
   a.skip = skip; a.skip_stride = skip_stride;
   a.ticket = plan->ticket;
-  const bool use_fused = !getenv("MO_FORCE_GENERIC") && !(plan->desc.flags & MO_PLAN_FORCE_GENERIC) && mo::fused_supported(a, plan->desc.dtype);
+  const KernelChoice choice = choose_kernel(plan, a);
+  const bool use_fused = choice == KERNEL_FUSED_F64;
   if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch
     if (batch > plan->desc.max_batch) return fail(MO_ERR_INVALID_ARGUMENT, "batch %lld > plan max_batch %lld", (long long)batch, (long long)plan->desc.max_batch);
     const size_t n = (size_t)plan->desc.n;
     MO_HIP_CHECK(hipSetDevice(plan->desc.device));
-    if (!plan->G_scratch) {
-      MO_HIP_CHECK(hipMalloc(&plan->G_scratch, (size_t)plan->desc.max_batch * n * n * plan->elem));
-      MO_HIP_CHECK(hipMalloc(&plan->c_scratch, (size_t)plan->desc.max_batch * n * plan->elem));
+    if (!plan->G_scratch || !plan->c_scratch) {  // both or neither: a half-made pair would hand the kernel a NULL c_out
+      void *g = nullptr, *c = nullptr;
+      if (hipMalloc(&g, (size_t)plan->desc.max_batch * n * n * plan->elem) != hipSuccess ||
+          hipMalloc(&c, (size_t)plan->desc.max_batch * n * plan->elem) != hipSuccess) {
+        if (g) (void)hipFree(g);
+        (void)hipGetLastError();
+        return fail(MO_ERR_HIP, "hipMalloc of the linearisation scratch failed (max_batch %lld, n %zu)", (long long)plan->desc.max_batch, n);
+      }
+      if (plan->G_scratch) (void)hipFree(plan->G_scratch);
+      if (plan->c_scratch) (void)hipFree(plan->c_scratch);
+      plan->G_scratch = g; plan->c_scratch = c;
     }
     a.G_out = plan->G_scratch; a.G_out_stride = (long long)(n * n); a.G_out_ld = (int)n;
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
@@ -434,7 +468,7 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
     }
     a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_problem;
   }
-  return launch(plan, a, stream);  // fused Solve kernel (fp64, n <= 128), generic kernel otherwise
+  return launch_chosen(plan, a, choice, stream);  // fused Solve kernel (fp64, n <= 128), generic kernel otherwise
 }
 }  // namespace
 

@@ -158,23 +158,62 @@ def test_synthetic_step_vs_numpy_full_system(cfg, use_inverse):
             assert abs(a - min([1.0] + cand)) < 1e-12
 
 
-def test_generated_problems_kkt_certificate():
-    """Portable restatement of TestGeneratedProblems (qp_test.cc:527-574): both initial-guess methods run <= 30
-    iterations on random N=8 QPs; every run that reports SATISFIED_KKT_TOL is certified optimal by an independent numpy
-    check of the KKT conditions of the convex QP (stationarity, feasibility, z >= 0, complementarity), and
-    SOLVE_EQUALITY_CONSTRAINED needs fewer iterations in total than NAIVE (qp_test.cc:572-573)."""
+def test_generated_problems():
+    """TestGeneratedProblems (qp_test.cc:527-574) with the reference's own assertions: 1000 random N=8 QPs (diagonal PD
+    scaling, see tests/helpers.py), COMPLEMENTARITY, termination_kkt_tol 1e-12, max 30 iterations, both initial-guess
+    methods: |x - x*|inf <= 5e-5 and |s|inf <= 5e-5 on every problem (qp_test.cc:555-562; every bound is active at x*),
+    and 4 * iterations(SOLVE_EQUALITY_CONSTRAINED) < iterations(NAIVE) (qp_test.cc:572-573)."""
     from tests.helpers import generated_qps
     n = 8
     totals = {orc.GUESS_NAIVE: 0, orc.GUESS_SOLVE_EQUALITY_CONSTRAINED: 0}
-    satisfied = 0
-    runs = 0
-    for (G, c, cons) in generated_qps(150, n):
+    for p, (G, c, cons, x_solution) in enumerate(generated_qps(1000, n)):
         for method in totals:
             s = orc.Solver(orc.QP(G=G, c=c, cons_var=[q[0] for q in cons], cons_a=[q[1] for q in cons],
                                   cons_b=[q[2] for q in cons]))
             term, its = s.solve(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method)
             totals[method] += len(its)
-            runs += 1
+            assert term in (orc.SATISFIED_KKT_TOL, orc.MAX_ITERATIONS) and len(its) <= 30
+            m = len(cons)
+            assert np.abs(s.variables[:n] - x_solution).max() <= 5e-5, (p, method, term)
+            if m:
+                assert np.abs(s.variables[n:n + m]).max() <= 5e-5, (p, method, term)
+    assert totals[orc.GUESS_SOLVE_EQUALITY_CONSTRAINED] * 4 < totals[orc.GUESS_NAIVE], totals
+
+
+def test_generated_problems_other_streams():
+    """The same construction on two other random streams: a run may stop at MAX_ITERATIONS (about 1 NAIVE run in 2000
+    does, see tests/helpers.py), but every run that reports SATISFIED_KKT_TOL meets the reference's 5e-5 bounds."""
+    from tests.helpers import generated_qps
+    n = 8
+    at_max = runs = 0
+    for seed in (1234, 7):
+        for (G, c, cons, x_solution) in generated_qps(300, n, seed=seed):
+            for method in (orc.GUESS_NAIVE, orc.GUESS_SOLVE_EQUALITY_CONSTRAINED):
+                s = orc.Solver(orc.QP(G=G, c=c, cons_var=[q[0] for q in cons], cons_a=[q[1] for q in cons],
+                                      cons_b=[q[2] for q in cons]))
+                term, its = s.solve(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method)
+                runs += 1
+                if term == orc.MAX_ITERATIONS:
+                    at_max += 1
+                    continue
+                assert np.abs(s.variables[:n] - x_solution).max() <= 5e-5
+                if cons:
+                    assert np.abs(s.variables[n:n + len(cons)]).max() <= 5e-5
+    assert at_max <= 0.005 * runs, (at_max, runs)
+
+
+def test_dense_generated_problems_kkt_certificate():
+    """OUR stress test, not a reference test: the dense-PD variant of the generator (cond(G) up to 1e11, coupled bounds).
+    Every run that reports SATISFIED_KKT_TOL is certified optimal by an independent numpy check of the KKT conditions of
+    the convex QP (stationarity, feasibility, z >= 0, complementarity)."""
+    from tests.helpers import dense_generated_qps
+    n = 8
+    satisfied = 0
+    for (G, c, cons, _) in dense_generated_qps(100, n):
+        for method in (orc.GUESS_NAIVE, orc.GUESS_SOLVE_EQUALITY_CONSTRAINED):
+            s = orc.Solver(orc.QP(G=G, c=c, cons_var=[q[0] for q in cons], cons_a=[q[1] for q in cons],
+                                  cons_b=[q[2] for q in cons]))
+            term, its = s.solve(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method)
             assert term in (orc.SATISFIED_KKT_TOL, orc.MAX_ITERATIONS)
             if term != orc.SATISFIED_KKT_TOL:
                 continue
@@ -189,8 +228,7 @@ def test_generated_problems_kkt_certificate():
                 assert z[i] >= 0                                          # dual feasibility
                 assert abs((a * x[v] + b) * z[i]) <= 1e-5 * scale         # complementarity
             assert np.abs(grad).max() <= 1e-9 * scale                     # stationarity
-    assert satisfied >= 0.5 * runs, (satisfied, runs)  # ill-conditioned draws (cond(G) > 1e7) stop at MAX_ITERATIONS
-    assert totals[orc.GUESS_SOLVE_EQUALITY_CONSTRAINED] < totals[orc.GUESS_NAIVE]
+    assert satisfied > 0
 
 
 def test_predictor_corrector_and_fixed_decrease_converge():
