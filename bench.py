@@ -2,15 +2,26 @@
 """bench.py -- batched dense KKT Newton steps/s on MI355X (BASELINE.json metric).
 
 A "step" = one pass of the hot path (mo_newton_step through the C ABI) over one batch of synthetic QPs that is already
-resident in HBM.  N=1 workload: BASELINE.json configs[2] (batch 65536, n=64 / 8 eq / 32 box, fp64, J-level input).
-N>1: every rank owns its own batch of the same size on its own GPU (weak scaling, no data-path collective -- the batch
-shards embarrassingly); value = problems all ranks processed / max-over-ranks wall time.
+resident in HBM.
+
+Workloads (`--config`; the default follows `--gpus`):
+  N = 1  -> cfg3 = BASELINE.json configs[2]: batch 65536, n=64 / 8 eq / 32 box, fp64, J-level input.
+  N > 1  -> cfg5 = BASELINE.json configs[4]: 2^20 QPs of the cfg3 shape IN TOTAL, sharded contiguously over the N ranks with
+            mini_opt_amd.sharding.shard_range (131072 per GPU at N = 8), no data-path collective ("scaling": "strong").
+            `--config cfg5 --gpus 1 --batch 131072` launches one config-5 shard on a single GPU.
+  cfg2 / cfg4 are the other single-GPU BASELINE configs (parity-test cases; runnable here for profiling).
+value = problems all ranks processed / max-over-ranks wall time.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: algorithmic bytes per launch / average launch duration
 measured with events on the launch stream, vs the 8 TB/s HBM peak) and `cpu_baseline` (the oracle's plain-C restatement
-of the reference step incl. the reference's explicit inverse, timed on the host cores on a bounded sample; rank 0, N=1).
+of the reference step incl. the reference's explicit inverse, timed on the host cores on a bounded sample; rank 0, N=1;
+with the 1-core and the direct-solve variants SURVEY.md 8(d) asks for).
+
+`--dry` rehearses the rank plumbing without a GPU (tests/test_bench_ranks_cpu.py: gloo, world size 2): the launch is replaced
+by a no-op and no device is touched; the JSON line then carries "dry": true and no measurement.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,22 +33,47 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 = 32 cycles
 FP64_PEAK_TFLOPS = 78.6  # datasheet fp64 matrix = vector rate; tools/microbench.hip measures 64 cycles per v_mfma_f64_16x16x4_f64
+CFG5_TOTAL = 1 << 20   # BASELINE.json configs[4]
+BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}
 
 
-def measured_traffic_bytes(kernel_name: str, config: str, batch: int):
+def kernel_source_digest() -> str:
+    """sha256 over the kernel sources: a committed PMC summary is only quoted while the kernels it measured are unchanged."""
+    h = hashlib.sha256()
+    for name in ("kkt_fused.hip", "kkt_fused_f32.hip", "kkt_generic.hip", "mo_kernels.h"):
+        with open(os.path.join(ROOT, "mini_opt_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel_name: str, config: str, batch: int):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected with tools/profile_pmc.sh):
     FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports half of wide 16 B/lane streaming reads, MI355X_MICROARCH.md HBM section)
-    + WRITE_SIZE [KB] x 1024.  Only valid for the workload the counters were collected on; otherwise None."""
-    if config != "cfg3" or batch != 65536 or not kernel_name.startswith("fused"):
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_fused_cfg3_pmc_summary.json")
+    + WRITE_SIZE [KB] x 1024.  The counters cannot be read from inside this process, so the figure comes from the committed
+    summary -- and only while it is valid: same workload, and the kernel sources still hash to what the summary recorded.
+    Returns (bytes or None, provenance dict)."""
+    src = {"source": None}
+    if not kernel_name.startswith("fused"):
+        return None, src
+    want = {"cfg3": "r02_step_cfg3_pmc_summary.json", "cfg5": "r02_step_cfg5shard_pmc_summary.json",
+            "cfg2": "r02_step_cfg2_pmc_summary.json"}.get(config)
+    if want is None:
+        return None, src
+    path = os.path.join(ROOT, "profiles", want)
     try:
         with open(path) as f:
             summ = json.load(f)
+        meta = summ.get("_meta", {})
+        src = {"source": "profiles/" + want, "collected_at_kernel_digest": meta.get("kernel_digest"),
+               "collected_at_commit": meta.get("git_head"), "batch": meta.get("batch")}
+        if meta.get("kernel_digest") != kernel_source_digest() or int(meta.get("batch", -1)) != batch:
+            src["stale"] = True
+            return None, src
         row = next(v for k, v in summ.items() if "kkt_fused" in k)
-        return float(row["FETCH_SIZE"]) * 1024.0 * 2.0 + float(row["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
+        return float(row["FETCH_SIZE"]) * 1024.0 * 2.0 + float(row["WRITE_SIZE"]) * 1024.0, src
+    except Exception as exc:  # no summary for this workload (yet): traffic stays null
+        src["error"] = repr(exc)
+        return None, src
 
 
 def usable_cores() -> int:
@@ -59,79 +95,122 @@ def usable_cores() -> int:
     return n
 
 
+def plan_workload(args, info):
+    """What this rank runs: (config name, shape dict, per-rank batch, total batch, scaling label, workload text)."""
+    from mini_opt_amd import sharding, synth
+    config = args.config or ("cfg3" if info.world_size == 1 else "cfg5")
+    if config == "cfg5":
+        shape = dict(synth.CONFIGS["cfg3"])
+        if args.batch:   # one explicit shard per rank (e.g. --gpus 1 --batch 131072 = the 8-GPU shard on one GPU)
+            batch, total = args.batch, args.batch * info.world_size
+        else:
+            b0, b1 = sharding.shard_range(CFG5_TOTAL, info.rank, info.world_size)
+            batch, total = b1 - b0, CFG5_TOTAL
+        scaling = "strong"
+        text = (f"BASELINE configs[4]: {total} QPs in total, n={shape['n']} / {shape['k']} eq / {shape['m']} box, m_r={shape['m_r']}, fp64, "
+                f"sharded contiguously over {info.world_size} GPU(s) ({batch} on rank {info.rank}), no collectives, J-level input "
+                f"(row-major J), one mo_newton_step launch per step and rank")
+    else:
+        shape = dict(synth.CONFIGS[config])
+        batch = args.batch or shape["batch"]
+        total = batch * info.world_size
+        scaling = "weak"
+        text = (f"BASELINE configs[{BASELINE_INDEX[config]}]: batch={batch} per GPU, n={shape['n']} / {shape['k']} eq / {shape['m']} box, "
+                f"m_r={shape['m_r']}, J-level input (row-major J), one mo_newton_step launch per step")
+    return config, shape, batch, total, scaling, text
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--config", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="default: cfg3 at --gpus 1, cfg5 (2^20 QPs in total, sharded) at --gpus > 1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--parity-sample", type=int, default=256)
+    ap.add_argument("--dry", action="store_true", help="rank plumbing only: no GPU, the launch is a no-op (CPU tests)")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-
-    from mini_opt_amd import qp as Q
-    from mini_opt_amd import sharding, synth
+    from mini_opt_amd import sharding
 
     info = sharding.RankInfo.from_env()
-    if info.world_size != args.gpus and info.world_size > 1:
-        raise SystemExit(f"WORLD_SIZE={info.world_size} but --gpus {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # one process per GPU; on a box with fewer GPUs than ranks (rehearsals only) ranks wrap around the visible devices
-    dev_index = info.local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    # RCCL ("nccl" on ROCm) carries only the timing barrier and two scalar reductions; MO_BENCH_BACKEND=gloo rehearses the
-    # multi-rank path on a single-GPU box
-    backend = os.environ.get("MO_BENCH_BACKEND", "nccl")
-    dist = sharding.init_process_group(info, backend)
-
-    cfg = synth.CONFIGS[args.config]
+    if info.world_size != args.gpus:
+        # one process per GPU: --gpus N must come with a launcher that sets WORLD_SIZE = N (python -m torch.distributed.run
+        # --nproc-per-node N ...); a bare `bench.py --gpus 8` would silently measure one GPU
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={info.world_size}; launch with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+    config, cfg, batch, total_batch, scaling, workload = plan_workload(args, info)
     n, k, m, m_r = cfg["n"], cfg["k"], cfg["m"], cfg["m_r"]
-    dtype = torch.float64 if cfg["dtype"] == "f64" else torch.float32
     T = 8 if cfg["dtype"] == "f64" else 4
-    batch = args.batch or cfg["batch"]
 
-    prob, vars_, mu = synth.make_batch_torch(n, k, m, m_r, batch, dev, dtype, seed=synth.SEED + 1000 * info.rank)
-    solver = Q.QPInteriorPointSolver(prob, force_generic=args.force_generic)
-    solver.SetVariables(vars_)
-    kernel_name = solver.step_kernel()
+    if args.dry:
+        # RCCL is replaced by gloo and the launch by a no-op; everything else (sharding, barriers, MAX / SUM, the JSON line) is the
+        # code the GPU run executes
+        dist = sharding.init_process_group(info, os.environ.get("MO_BENCH_BACKEND", "gloo"))
+        dev = None
+        kernel_name = "dry"
 
-    def step():
-        return solver.NewtonStep(mu, 0.995)
+        def step():
+            return None, None, None
+        sync = lambda: None
+    else:
+        import torch
+
+        from mini_opt_amd import qp as Q
+        from mini_opt_amd import synth
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        # one process per GPU; on a box with fewer GPUs than ranks (rehearsals only) ranks wrap around the visible devices
+        dev_index = info.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        # RCCL ("nccl" on ROCm) carries only the timing barrier and two scalar reductions; MO_BENCH_BACKEND=gloo rehearses the
+        # multi-rank path on a single-GPU box
+        backend = os.environ.get("MO_BENCH_BACKEND", "nccl")
+        dist = sharding.init_process_group(info, backend)
+        dtype = torch.float64 if cfg["dtype"] == "f64" else torch.float32
+        prob, vars_, mu = synth.make_batch_torch(n, k, m, m_r, batch, dev, dtype, seed=synth.SEED + 1000 * info.rank)
+        solver = Q.QPInteriorPointSolver(prob, force_generic=args.force_generic)
+        solver.SetVariables(vars_)
+        kernel_name = solver.step_kernel()
+
+        def step():
+            return solver.NewtonStep(mu, 0.995)
+        sync = torch.cuda.synchronize
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if info.world_size > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    if not args.dry:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for e0, e1 in evs:  # events sit on torch's current stream == the stream handed to the C ABI
-        e0.record()
-        delta, alpha, status = step()
-        e1.record()
-    torch.cuda.synchronize()
+    if args.dry:
+        for _ in range(args.steps):
+            step()
+        delta = alpha = status = None
+    else:
+        for e0, e1 in evs:  # events sit on torch's current stream == the stream handed to the C ABI
+            e0.record()
+            delta, alpha, status = step()
+            e1.record()
+    sync()
     if info.world_size > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, dev if backend == "nccl" else None)
-    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    reduce_dev = dev if (not args.dry and os.environ.get("MO_BENCH_BACKEND", "nccl") == "nccl") else None
+    elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, reduce_dev)
 
-    ok = int((status == 0).sum().item())
     out = None
     if info.rank == 0:
-        alg_bytes = synth.algorithmic_bytes(n, k, m, m_r, T)
-        achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "batched dense KKT Newton steps/sec, n=64 fp64" if args.config == "cfg3" else f"batched dense KKT Newton steps/sec ({args.config})",
+            "metric": "batched dense KKT Newton steps/sec, n=64 fp64" if config in ("cfg3", "cfg5") else f"batched dense KKT Newton steps/sec ({config})",
             "value": total_units / elapsed_max,
             "unit": "steps/s",
             "n_gpus": info.world_size,
@@ -139,26 +218,45 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": cfg["dtype"],
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{ {'cfg2': 1, 'cfg3': 2, 'cfg4': 3}[args.config] }]: batch={batch} per GPU, n={n} / {k} eq / {m} box, m_r={m_r}, J-level input (row-major J), one mo_newton_step launch per step",
-                       "kernel": kernel_name, "batch_per_gpu": batch, "n": n, "k": k, "m": m, "m_r": m_r,
-                       "parallelism": f"batch-sharded x{info.world_size}, no collectives"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(kernel_name, args.config, batch),
-                         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes * batch,
-                         "kernel_ms": kernel_ms,
-                         "fp64_tflops": synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12,
-                         "fp64_frac_of_peak": synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-            "status_ok": ok, "status_total": batch,
+            "config": {"workload": workload, "name": config, "kernel": kernel_name, "batch_per_gpu": batch, "batch_total": total_batch,
+                       "n": n, "k": k, "m": m, "m_r": m_r, "parallelism": f"batch-sharded x{info.world_size}, no collectives"},
         }
+    if args.dry:
+        if info.rank == 0:
+            out["dry"] = True
+            out["value"] = None  # nothing was measured
+            out["units_per_step_all_ranks"] = total_units // args.steps
+            print(json.dumps(out), flush=True)
+        if info.world_size > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import numpy as np
+    from mini_opt_amd import synth
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    ok = int((status == 0).sum().item())
+    if info.rank == 0:
+        alg_bytes = synth.algorithmic_bytes(n, k, m, m_r, T)
+        achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(kernel_name, config, batch)
+        flops = synth.algorithmic_flops(n, k, m, m_r)
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
+                           "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes * batch,
+                           "kernel_ms": kernel_ms, "scope": "rank 0's launches" if info.world_size > 1 else "the launch",
+                           "fp64_tflops": flops * batch / (kernel_ms * 1e-3) / 1e12,
+                           "fp64_frac_of_peak": flops * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        out["status_ok"], out["status_total"] = ok, batch
         if cfg["dtype"] == "f32":  # cfg 4 is bound by the fp32 matrix cores (AI 37.5 flop/B vs ridge 19.7), not by HBM
-            tf = synth.algorithmic_flops(n, k, m, m_r) * batch / (kernel_ms * 1e-3) / 1e12
+            tf = flops * batch / (kernel_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "algorithmic_flops_per_step": synth.algorithmic_flops(n, k, m, m_r), "kernel_ms": kernel_ms,
+                               "algorithmic_flops_per_step": flops, "kernel_ms": kernel_ms,
                                "hbm_gbs_algorithmic": achieved}
 
         # The cpu_baseline leg (rank 0 at N = 1 only; --no-cpu-baseline skips it entirely, e.g. under rocprofv3): the ONLY place where
@@ -179,32 +277,39 @@ def main():
             err = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
             out["parity"] = {"sample": ns, "max_rel_inf": float(err.max()), "tolerance": 1e-10 if T == 8 else 2e-3,
                              "passed": bool(err.max() < (1e-10 if T == 8 else 2e-3))}
-            if True:
-                cores = usable_cores()
-                pilot = min(batch, 4 * cores)
-                hs = lambda t, cnt: t[:cnt].double().cpu().numpy()
+            cores = usable_cores()
+            hs = lambda t, cnt: t[:cnt].double().cpu().numpy()
 
-                def run_cpu(cnt):
-                    a = dict(J=hs(prob.J, cnt), r=hs(prob.r, cnt), lam=prob.lam, A_eq=hs(prob.A_eq, cnt), b_eq=hs(prob.b_eq, cnt),
-                             cons_var=prob.cons_var[:cnt].cpu().numpy(), cons_a=hs(prob.cons_a, cnt), cons_b=hs(prob.cons_b, cnt),
-                             vars_=hs(vars_, cnt), mu=hs(mu, cnt), use_inverse=True, num_threads=cores)
-                    t = time.perf_counter()
-                    _, _, _, used = orc.batched_newton_step(n, k, m, **a)
-                    return time.perf_counter() - t, used
+            def run_cpu(cnt, threads, use_inverse):
+                a = dict(J=hs(prob.J, cnt), r=hs(prob.r, cnt), lam=prob.lam, A_eq=hs(prob.A_eq, cnt), b_eq=hs(prob.b_eq, cnt),
+                         cons_var=prob.cons_var[:cnt].cpu().numpy(), cons_a=hs(prob.cons_a, cnt), cons_b=hs(prob.cons_b, cnt),
+                         vars_=hs(vars_, cnt), mu=hs(mu, cnt), use_inverse=use_inverse, num_threads=threads)
+                t = time.perf_counter()
+                _, _, _, used = orc.batched_newton_step(n, k, m, **a)
+                return time.perf_counter() - t, used
 
-                run_cpu(pilot)
-                tp, used = run_cpu(pilot)
-                cnt = int(min(batch, max(pilot, pilot * args.cpu_seconds / 3 / max(tp, 1e-6))))
-                reps = []
-                t_total = 0.0
-                while len(reps) < 3 or (t_total < args.cpu_seconds and len(reps) < 50):
-                    t, used = run_cpu(cnt)
+            def timed_variant(threads, use_inverse, seconds):
+                pilot = min(batch, 4 * max(threads, 1))
+                run_cpu(pilot, threads, use_inverse)
+                tp, used = run_cpu(pilot, threads, use_inverse)
+                cnt = int(min(batch, max(pilot, pilot * seconds / 3 / max(tp, 1e-6))))
+                reps, t_total = [], 0.0
+                while len(reps) < 3 or (t_total < seconds and len(reps) < 50):
+                    t, used = run_cpu(cnt, threads, use_inverse)
                     reps.append(t)
                     t_total += t
-                out["cpu_baseline"] = {
-                    "value": cnt / float(np.median(reps)), "unit": "steps/s", "cores": used, "kind": "port",
-                    "sample": f"first {cnt} problems of the same batch, {len(reps)} repeats (median), OpenMP over problems; "
-                              "plain-C restatement of the reference step incl. its explicit inverse (qp.cc:310-311); Eigen itself is absent from the image"}
+                return {"value": cnt / float(np.median(reps)), "unit": "steps/s", "cores": used,
+                        "sample": f"first {cnt} problems of the same batch, {len(reps)} repeats (median)"}
+
+            # all cores and one core, with the reference's explicit inverse (qp.cc:310-311) and with a direct solve
+            main_v = timed_variant(cores, True, args.cpu_seconds * 0.5)
+            out["cpu_baseline"] = {
+                **main_v, "kind": "port",
+                "sample": main_v["sample"] + ", OpenMP over problems; plain-C restatement of the reference step incl. its explicit "
+                          "inverse (qp.cc:310-311); Eigen itself is absent from the image",
+                "one_core": timed_variant(1, True, args.cpu_seconds * 0.15),
+                "direct": timed_variant(cores, False, args.cpu_seconds * 0.2),
+                "direct_one_core": timed_variant(1, False, args.cpu_seconds * 0.15)}
         except StopIteration:
             pass
         except Exception as exc:  # the oracle is only the checker; never let it hide the measurement

@@ -1,0 +1,57 @@
+"""bench.py's rank path on CPU (gloo, world size 2): the very code the driver launches with `python -m torch.distributed.run ...
+bench.py --gpus N`, with `--dry` swapping the device launch for a no-op.  Covers the config-5 sharding (2^20 QPs in total,
+BASELINE.json configs[4]), the barriers, the MAX / SUM reductions and the JSON line; no GPU, no oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra):
+    env = dict(os.environ, MO_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--dry"] + extra
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout      # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_default_to_config5_sharded():
+    out = _run(2, [])
+    assert out["dry"] is True and out["value"] is None
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "strong" and out["config"]["name"] == "cfg5"
+    assert "configs[4]" in out["config"]["workload"]
+    assert out["config"]["batch_total"] == 2 ** 20 and out["config"]["batch_per_gpu"] == 2 ** 19
+    assert out["units_per_step_all_ranks"] == 2 ** 20      # SUM over ranks of the shard sizes: the whole of config 5
+    assert (out["config"]["n"], out["config"]["k"], out["config"]["m"], out["config"]["m_r"]) == (64, 8, 32, 128)
+    assert out["dtype"] == "f64" and out["unit"] == "steps/s" and out["higher_is_better"] is True
+
+
+def test_two_ranks_weak_scaling_config():
+    out = _run(2, ["--config", "cfg3"])
+    assert out["scaling"] == "weak" and out["config"]["batch_per_gpu"] == 65536 and out["config"]["batch_total"] == 2 * 65536
+    assert "configs[2]" in out["config"]["workload"]
+
+
+def test_gpus_without_launcher_is_an_error():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr

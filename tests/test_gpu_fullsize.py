@@ -48,8 +48,14 @@ def newton_equation_residuals(prob, vars_, mu, delta, chunk=8192):
     return worst.cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg,batch", [("cfg2", 4096), ("cfg3", 65536), ("cfg3", 70001)])
+@pytest.mark.parametrize("cfg,batch", [("cfg2", 4096), ("cfg3", 65536), ("cfg3", 70001), ("cfg3", 131072)],
+                         ids=["cfg2", "cfg3", "cfg3-ragged", "cfg5-shard"])
 def test_full_batch_satisfies_newton_equations(cfg, batch):
+    """The last case is ONE shard of BASELINE.json configs[4] (2^20 QPs of the cfg3 shape over 8 GPUs = 131072 problems, 9.6 GB of
+    J, per GPU -- sharding.shard_range(2**20, r, 8)), launched as a single mo_newton_step like `bench.py --gpus 8` does per rank."""
+    if batch == 131072:
+        from mini_opt_amd import sharding
+        assert [b - a for a, b in (sharding.shard_range(2 ** 20, r, 8) for r in range(8))] == [batch] * 8
     d = synth.CONFIGS[cfg]
     dev = torch.device("cuda:0")
     prob, vars_, mu = synth.make_batch_torch(d["n"], d["k"], d["m"], d["m_r"], batch, dev, torch.float64, seed=1234 + batch)
