@@ -359,8 +359,8 @@ def test_batched_solve_dense_generated_problems():
             o = orc.Solver(orc.QP(G=Gi, c=ci, cons_var=[q[0] for q in cons], cons_a=[q[1] for q in cons],
                                   cons_b=[q[2] for q in cons]))
             t, its = o.solve(termination_kkt_tol=1e-12, max_iterations=30, initial_guess_method=method)
-            if t == term[i] and len(its) == nit[i]:
-                np.testing.assert_allclose(v[i, :n], o.variables[:n], rtol=1e-6, atol=1e-7)
+            if t == term[i] and len(its) == nit[i]:  # cond(G) up to 1e11: agreement to cond * eps of the largest component
+                assert np.abs(v[i, :n] - o.variables[:n]).max() <= 1e-5 * max(1.0, np.abs(o.variables[:n]).max())
             if term[i] != Q.SATISFIED_KKT_TOL:
                 continue
             certified += 1
