@@ -325,12 +325,13 @@ class QPNullSpaceSolver:
         return self.x_
 
 
-def linearize(problem: BatchedQP):
+def linearize(problem: BatchedQP, force_generic: bool = False):
     """Cost part of LinearizeAndFillQP (nonlinear.cc:182-189): returns (G [B,n,n] col-major lower, c [B,n], 0.5|r|^2 [B])."""
     lib = L.lib()
     ref = problem.J
     B, n = int(ref.shape[0]), problem.n
-    desc = L.PlanDesc(n, 0, 0, problem.m_r, _DT[problem.dtype], ref.device.index or 0, 0, 0, B)
+    desc = L.PlanDesc(n, 0, 0, problem.m_r, _DT[problem.dtype], ref.device.index or 0,
+                      L.MO_PLAN_FORCE_GENERIC if force_generic else 0, 0, B)
     plan = C.c_void_p()
     L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
     try:

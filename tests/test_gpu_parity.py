@@ -82,6 +82,53 @@ def test_elimination_cases(case, force_generic):
     assert np.all(d[n:n + m] == 0) and np.all(d[n + m + k:] == 0)
 
 
+# ------------------------------------------------------------------ the reference's KATs that so far only pinned the oracle
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_compute_alpha_kat_on_device(force_generic):
+    """TestComputeAlpha (qp_test.cc:244-249: x = (1, .8, 1.2), dx = (-2, .6, -1.3): alpha = 0.5 at tau = 1, 0.45 at tau = 0.9) through
+    mo_newton_step: a batch-1 QP built so that the step's (s, ds) ARE the KAT's (x, dx) -- G = I, c = -2 dx, constraints x_i + s_i >= 0
+    at x = 0 with z = s and mu = 0 give (1 + z/s) dx_i = -c_i, ds = dx (qp.cc:337-342, 361) -- so the primal step length the kernel
+    returns is ComputeAlpha(s, ds, tau) (qp.cc:485-507)."""
+    g = load("alpha.json")
+    h = g["head"]
+    xk, dxk = np.array(g["x"][:h]), np.array(g["dx"][:h])
+    prob = Q.BatchedQP(n=h, k=0, m=h, G=T(np.eye(h)[None]), c=T((-2.0 * dxk)[None]),
+                       cons_var=T(np.arange(h, dtype=np.int32)[None], torch.int32), cons_a=T(np.ones((1, h))), cons_b=T(xk[None]))
+    s = Q.QPInteriorPointSolver(prob, force_generic=force_generic)
+    s.SetVariables(T(np.concatenate([np.zeros(h), xk, xk])[None]))   # [x | s | z]
+    for c in g["cases"]:
+        delta, alpha, status = s.NewtonStep(0.0, c["tau"])
+        assert int(status[0]) == 0
+        d = delta.cpu().numpy()[0]
+        np.testing.assert_allclose(d[h:2 * h], dxk, rtol=0, atol=1e-15)    # ds is the KAT's dx
+        assert abs(float(alpha[0, 0]) - c["alpha"]) < g["tol_abs"], (c, float(alpha[0, 0]))
+
+
+@pytest.mark.parametrize("case", load("residual.json"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_update_hessian_kat_on_device(case, force_generic):
+    """residual_test.cc:51-182 through mo_linearize: the residual's local Jacobian scattered into the dense stack by its index list
+    (what UpdateHessian's gr / gc lookup does, residual.hpp:206-222) gives the reference's J^T J (lower triangle; strict upper exactly 0,
+    residual_test.cc:130-134; cells of untouched variables exactly 0, :143-147), J^T r and 0.5 |r|^2."""
+    n = case["full_size"]
+    Jl = np.array(case["J"])
+    Jd = np.zeros((Jl.shape[0], n))
+    for l, gidx in enumerate(case["index"]):
+        Jd[:, gidx] += Jl[:, l]
+    prob = Q.BatchedQP(n=n, k=0, m=0, J=T(Jd[None]), r=T(np.array(case["r"])[None]), lam=0.0)
+    G, c, half = Q.linearize(prob, force_generic=force_generic)
+    H = G.cpu().numpy()[0].T            # column-major G -> H[row, col]
+    np.testing.assert_allclose(H, np.array(case["expected_H_lower"]), rtol=0, atol=case["tol_abs"])
+    assert np.all(np.triu(H, 1) == 0)
+    np.testing.assert_allclose(c.cpu().numpy()[0], case["expected_b"], rtol=0, atol=case["tol_abs"])
+    assert abs(float(half[0]) - case["expected_half_sq"]) < 1e-14
+    mask = np.zeros((n, n), bool)
+    for i in case["index"]:
+        for j in case["index"]:
+            mask[i, j] = True
+    assert np.all(H[~mask] == 0)
+
+
 # ------------------------------------------------------------------ synthetic fixtures (numpy full-system LU)
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4"])
 @pytest.mark.parametrize("force_generic", [True, False])
