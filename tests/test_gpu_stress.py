@@ -1,0 +1,127 @@
+"""Where the un-pivoted block LDL^T and the x+ form of the step kernel could differ from the reference: states from
+late interior-point iterations, ill-conditioned G, rank-deficient J^T J.  Every device variant -- fused step (x+ form), generic step,
+fused Iterate (the reference's residual form) -- is measured against a long-double solve of the unreduced Newton system
+(tests/stress_cases.py::truth_direction) next to the oracle's two variants (Eigen-style pivoted LDL^T + explicit inverse / direct solve).
+
+Tolerance model (DESIGN.md section 2 has the measured table): every formulation, the reference's included, evaluates quantities of size
+|K| |x| to get a direction of size |delta|, so   err_rel_inf(delta) <= C eps max(1, |x| / |delta|)   with eps = 2^-53 and C a modest
+constant, plus the usual C eps cond(K) of the solve.  The bar for the device is twofold: inside that model, and never more than a small
+factor worse than the reference arithmetic itself on the same input."""
+import numpy as np
+import pytest
+import torch
+
+from mini_opt_amd import qp as Q
+from oracle import oracle as orc
+from tests import stress_cases as S
+
+pytestmark = pytest.mark.gpu
+EPS = 2.0 ** -53
+
+
+def T(a, dt=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
+
+
+def device_problem(hb):
+    return Q.BatchedQP(n=hb.n, k=hb.k, m=hb.m, J=T(hb.J), r=T(hb.r), lam=hb.lam, A_eq=T(hb.A_eq), b_eq=T(hb.b_eq),
+                       cons_var=T(hb.cons_var, torch.int32), cons_a=T(hb.cons_a), cons_b=T(hb.cons_b))
+
+
+def directions(hb):
+    """{variant: delta [B, V]} of the three device formulations; every status word must be OK."""
+    out = {}
+    for label, force in (("fused_step", False), ("generic_step", True)):
+        s = Q.QPInteriorPointSolver(device_problem(hb), force_generic=force)
+        assert (s.step_kernel() == "generic") == force
+        s.SetVariables(T(hb.vars))
+        delta, _, status = s.NewtonStep(T(hb.mu), 0.995)
+        assert torch.all(status == 0), label
+        out[label] = delta.cpu().numpy().copy()
+    s = Q.QPInteriorPointSolver(device_problem(hb))
+    s.SetVariables(T(hb.vars))
+    _, status = s.Iterate(T(hb.mu), Q.COMPLEMENTARITY)
+    assert torch.all(status == 0)
+    out["fused_iterate"] = s.delta_.cpu().numpy().copy()
+    return out
+
+
+def per_problem(hb, p):
+    """(truth delta, {oracle variant: error}, cond of the reduced KKT matrix, |x| / |dx|)."""
+    n, k, m = hb.n, hb.k, hb.m
+    G, c, A, b, cv, ca, cb = S.dense_problem(hb, p)
+    tr = S.truth_direction(G, c, A, b, cv, ca, cb, hb.vars[p], hb.mu[p])
+    Gl, cl, _ = orc.linearize_dense(hb.J[p], hb.r[p], hb.lam)
+    o = orc.Solver(orc.QP(G=Gl, c=cl, A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=cv, cons_a=ca, cons_b=cb))
+    errs = {}
+    for inv in (True, False):
+        st, d, _ = o.newton_step(hb.vars[p], hb.mu[p], 0.995, inv)
+        assert st == 0
+        errs["inverse" if inv else "direct"] = np.abs(d - tr).max() / np.abs(tr).max()
+    v = hb.vars[p]
+    Sig = np.zeros(n)
+    np.add.at(Sig, cv, ca * v[n + m + k:] / v[n:n + m] * ca)
+    H = np.zeros((n + k, n + k)); H[:n, :n] = G + np.diag(Sig); H[n:, :n] = A; H[:n, n:] = A.T
+    return tr, errs, np.linalg.cond(H), np.abs(v[:n]).max() / np.abs(tr[:n]).max()
+
+
+@pytest.mark.parametrize("cfg,iterations", [("cfg2", 6), ("cfg2", 9), ("cfg3", 8), ("cfg3", 11)])
+def test_step_on_late_interior_point_states(cfg, iterations):
+    """States after `iterations` IP iterations: z/s down to 1e-9, |x| / |delta| from 1e5 to 1e11.  Both the x+ form and the residual
+    form lose eps |x| / |delta| -- and so does the reference: the device stays within 20 eps |x|/|delta| and within 8x of the oracle."""
+    hb = S.late_states(cfg, 6, iterations)
+    dev = directions(hb)
+    for p in range(hb.batch):
+        tr, oerr, cond, ratio = per_problem(hb, p)
+        assert ratio > 1e4                                     # the case is what it claims to be
+        for label, d in dev.items():
+            err = np.abs(d[p] - tr).max() / np.abs(tr).max()
+            assert err <= 20 * EPS * ratio + 1e-12, (label, p, err, ratio)
+            assert err <= 8 * max(oerr.values()) + 1e-12, (label, p, err, oerr)
+
+
+@pytest.mark.parametrize("n,k,m,m_r,log10_cond", [(32, 4, 16, 64, 6), (64, 8, 32, 128, 8), (32, 4, 16, 64, 10), (64, 8, 32, 128, 10)])
+def test_step_on_ill_conditioned_hessians(n, k, m, m_r, log10_cond):
+    """cond(G) 1e6 ... 3e10 (cond of the reduced KKT matrix up to 3e9): natural pivot order loses nothing the |H_ii|-ordered oracle keeps --
+    the BASELINE tolerance of 1e-10 holds up to cond(K) ~ 1e9 (beyond it the bound is 2 eps cond(K); observed 2e-10 at 3e9), and the
+    device is within 8x of the reference arithmetic (the x+ form is in fact 1000x closer to the truth here: it never forms G x)."""
+    hb = S.ill_conditioned(n, k, m, m_r, 6, log10_cond)
+    dev = directions(hb)
+    for p in range(hb.batch):
+        tr, oerr, cond, ratio = per_problem(hb, p)
+        assert cond > 10.0 ** (log10_cond - 2)
+        for label, d in dev.items():
+            err = np.abs(d[p] - tr).max() / np.abs(tr).max()
+            assert err <= max(1e-10, 2 * EPS * cond), (label, p, err, cond)
+            assert err <= 8 * max(oerr.values()) + 1e-13, (label, p, err, oerr)
+
+
+def test_step_with_rank_deficient_cost_and_regular_leading_block():
+    """lambda = 0, m_r < n, equalities: G = J^T J has rank 20 of 32 but G + Sigma is regular (a barrier term on every variable)."""
+    hb = S.rank_deficient(32, 4, 32, 20, 6)
+    dev = directions(hb)
+    for p in range(hb.batch):
+        tr, oerr, cond, _ = per_problem(hb, p)
+        for label, d in dev.items():
+            assert np.abs(d[p] - tr).max() / np.abs(tr).max() <= 1e-12, (label, p)
+
+
+def test_solve_on_ill_conditioned_hessians():
+    """mo_qp_solve (fused and generic) on cond(G) ~ 1e8 problems follows the oracle's Solve: same termination state and iteration
+    count for every problem, optimum within cond * eps."""
+    hb = S.ill_conditioned(64, 8, 32, 128, 8, 8)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=20, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED)
+    res = {}
+    for force in (False, True):
+        s = Q.QPInteriorPointSolver(device_problem(hb), force_generic=force)
+        out = s.Solve(Q.Params(**kw))
+        assert torch.all(out.status == 0)
+        res[force] = (s.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
+    for p in range(hb.batch):
+        Gl, cl, _ = orc.linearize_dense(hb.J[p], hb.r[p], hb.lam)
+        o = orc.Solver(orc.QP(G=Gl, c=cl, A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=hb.cons_var[p], cons_a=hb.cons_a[p], cons_b=hb.cons_b[p]))
+        term, its = o.solve(**kw)
+        for force in (False, True):
+            v, nit, tm = res[force]
+            assert tm[p] == term and nit[p] == len(its), (p, force, tm[p], term, nit[p], len(its))
+            assert np.abs(v[p][:hb.n] - o.variables[:hb.n]).max() <= 1e-6 * max(1.0, np.abs(o.variables[:hb.n]).max())
