@@ -210,10 +210,13 @@ int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_s
 /* Replaces QPNullSpaceSolver::Solve (qp.cc:679-729): minimise 1/2 x^T G x + c^T x subject to A_eq x + b_eq = 0 (k >= 1, no
  * inequalities; the plan's m is ignored).  x_out [batch][n] = QPNullSpaceSolver::variables(); termination [batch] =
  * QPNullSpaceTerminationState (structs.hpp:137-142): 0 SUCCESS, 1 NOT_POSITIVE_DEFINITE (x_out is NaN then).
- * The reference projects G into null(A_eq) with a pivoted Householder QR and Cholesky-factors the reduced Hessian; here the
- * same minimiser comes from the LDL^T of the KKT matrix, and "reduced Hessian positive definite" is read off its inertia
- * (exactly k negative pivots) -- same answers, no QR.  Rank-deficient A_eq (which the reference's rank-revealing QR
- * tolerates) is reported as NOT_POSITIVE_DEFINITE. */
+ * Same algorithm as the reference, one workgroup per problem with G and A_eq^T resident in LDS: Householder QR of A_eq^T with column
+ * pivoting (qp.cc:687; rank = Eigen's default threshold |R_jj| > |R|_max eps min(n, k), :697), u = Q1 R1^-T P^T (-b_eq) (:703-704),
+ * G_reduced = Q2^T G Q2 by two-sided application of the reflectors (:708), LLT that fails iff a pivot is <= 0 (:711-714 ->
+ * NOT_POSITIVE_DEFINITE), y from -(Q2^T (c + G u)) (:718-721), x = u + Q2 y (:725).  What decides SUCCESS is the reduced Hessian
+ * alone: a singular or indefinite G is fine when it is positive definite on null(A_eq).  k <= n is required; for a rank-deficient
+ * A_eq (rank r < k) the solve uses R's leading r x r block (the reference's k x k solve against Q1's r columns is a size mismatch
+ * there).  Limits: LDS-resident, (n | 1) (n + k) + 5 n + 4 k scalars <= 160 KiB (n = 128, k = 16 fits in fp64). */
 typedef enum { MO_NULLSPACE_SUCCESS = 0, MO_NULLSPACE_NOT_POSITIVE_DEFINITE = 1 } mo_nullspace_termination;
 int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, void* x_out, int64_t x_stride,
                        int32_t* termination, void* stream);
@@ -230,9 +233,10 @@ int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, voi
  * quadratic / cubic interpolation, the lambda state machine and the exit tests -- runs on the device.
  * fp64 plans only.  A problem whose QP fails (status != MO_STATUS_OK; the reference throws there) ends with
  * MO_NLS_QP_FAILURE and its QP status in status[p].  With equality constraints and no inequalities the reference switches
- * to QPNullSpaceSolver (nonlinear.cc:83-86); here the same step comes from the KKT factorisation and the penalty follows
- * the no-multiplier branch of SelectPenalty (nonlinear.cc:491-499) as the reference's does; a KKT matrix that cannot be
- * factorised there ends the problem with MO_NLS_QP_INDEFINITE (G = J^T J + lambda I is never indefinite, only singular). */
+ * to QPNullSpaceSolver (nonlinear.cc:83-86, 249-258) and so does this call (the null-space kernel behind mo_nullspace_solve: a
+ * singular G = J^T J is fine as long as the reduced Hessian is positive definite); the penalty then follows the no-multiplier
+ * branch of SelectPenalty (nonlinear.cc:491-499), and NOT_POSITIVE_DEFINITE ends the problem with MO_NLS_QP_INDEFINITE
+ * (nonlinear.cc:103-105). */
 typedef enum { MO_NLS_MAX_ITERATIONS = 0, MO_NLS_SATISFIED_ABSOLUTE_TOL = 1, MO_NLS_SATISFIED_RELATIVE_TOL = 2,
                MO_NLS_SATISFIED_FIRST_ORDER_TOL = 3, MO_NLS_MAX_LAMBDA = 4, MO_NLS_QP_INDEFINITE = 5,
                MO_NLS_USER_CALLBACK = 6, MO_NLS_QP_FAILURE = 7 } mo_nls_termination;   /* NLSTerminationState, structs.hpp:233-248 */

@@ -515,8 +515,6 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
     if (a.vars && MODE != MODE_LINEARIZE) {
       const T* vp = (const T*)a.vars + p * a.vars_stride;
       for (int i = tid; i < V; i += kThreads) w.vars[i] = vp[i];
-    } else if (MODE == MODE_STEP) {  // mo_nullspace_solve: the step from x = y = 0 IS the minimiser
-      for (int i = tid; i < V; i += kThreads) w.vars[i] = (T)0;
     }
     T mu_p = (T)0;
     if (a.mu) mu_p = ((const T*)a.mu)[p * a.mu_stride];
@@ -566,18 +564,6 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
         MO_GSTAMP(3);
         if (no_ineq) {
           st = assemble_and_factor(w, n, k, m, false, tid);
-          if (st == MO_STATUS_OK && (a.flags & MO_STEP_NULLSPACE)) {
-            // QPNullSpaceSolver's LLT of the reduced Hessian Z^T G Z succeeds iff it is positive definite (qp.cc:709-713), i.e.
-            // (A_eq of full row rank) iff the KKT matrix has inertia (n, k, 0): count the negative pivots of D (Sylvester).
-            int neg = 0;
-            for (int i = tid; i < n + k; i += kThreads) neg += (w.invd[i] < (T)0) ? 1 : 0;
-            neg = wave_sum(neg);
-            if ((tid & 63) == 0) atomicAdd(&w.iflag[4], neg);
-            __syncthreads();
-            if (w.iflag[4] != k) st = MO_STATUS_NOT_POSITIVE_DEFINITE;
-          } else if (a.flags & MO_STEP_NULLSPACE) {
-            st = MO_STATUS_NOT_POSITIVE_DEFINITE;  // a zero pivot: the reduced Hessian (or A_eq A_eq^T) is singular
-          }
           if (st == MO_STATUS_OK) solve_for_update(w, n, k, m, (T)0, false, tid);
           ip[0] = mu_p; ip[1] = 1; ip[2] = 1; ip[3] = ip[4] = ip[5] = nanT<T>();
         } else {
@@ -600,8 +586,7 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
       }
       if (a.delta) {
         T* dp = (T*)a.delta + p * a.delta_stride;
-        const int nout = (a.flags & MO_STEP_NULLSPACE) ? n : V;  // mo_nullspace_solve returns x only (QPNullSpaceSolver::variables())
-        for (int i = tid; i < nout; i += kThreads) dp[i] = st == MO_STATUS_OK ? w.delta[i] : nanT<T>();
+        for (int i = tid; i < V; i += kThreads) dp[i] = st == MO_STATUS_OK ? w.delta[i] : nanT<T>();
       }
       if (tid == 0) {  // constant indices only: a runtime-indexed register array would live in scratch
         if (a.alpha) {
@@ -724,6 +709,257 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
 #endif
 }
 
+
+// ---- QPNullSpaceSolver::Solve (qp.cc:679-729) ---------------------------------------------------------------------------------
+// One workgroup per problem, everything LDS-resident in the generic kernel's workspace (m = 0): G (full symmetric) in H[0:n, 0:n],
+// M = A_eq^T (n x k) in the rows n.. of H (M(i, q) = H[n + q + i ldh]).  The reference's steps, restated without forming Q:
+//   colPivHouseholderQr of A_eq^T (:687)       k Householder steps with column pivoting on the largest remaining column norm; reflectors
+//                                              stay in M below R (v_0 = 1 implicit); rank = #{|R_jj| > |R|_max eps min(n, k)} (Eigen's default)
+//   u = Q1 R1^-T P^T (-b_eq)       (:703-704)  forward substitution + the reflectors applied to [t; 0]
+//   G_reduced = Q2^T G Q2          (:708)      two-sided application of the reflectors to G (symmetric rank-2 updates), trailing block
+//   LLT, fails iff a pivot <= 0    (:711-714)  right-looking Cholesky in place -> MO_STATUS_NOT_POSITIVE_DEFINITE
+//   y = -(Q2^T (c + G u)), LL^T    (:718-721)  c + G u is formed BEFORE G is transformed; reflectors applied to it; two triangular solves
+//   x = u + Q2 y                   (:725)      the reflectors applied to [0; y]
+// A rank-deficient A_eq (rank r < k): Q1 = first r columns, R1 = leading r x r block (the reference's own k x k solve against Q1's r
+// columns is a size mismatch there -- an Eigen assertion --, so this follows the consistent reading: solve with R1 only).
+// Orders one wave's own LDS traffic: values another lane of the SAME wave stored are visible to the loads that follow.
+__device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// LDS layout of the null-space kernel: G (n x n, odd leading dimension) | M = A_eq^T (n x k, same leading dimension) | u, g, pv, wv,
+// cvec (n each) | beq, tau, pidx, nrm (k each) | J row chunk | 16 scalars | 8 flags.  Tighter than the generic (n + k)^2 workspace:
+// n = 128, k = 16 fits the 160 KiB of a CU.
+template <typename T>
+__host__ __device__ inline size_t nullspace_elems(int n, int k, int m_r) {
+  const int cr = chunk_rows_for(n, m_r, (int)sizeof(T));
+  return (size_t)odd_ld(n) * (n + k) + 5 * (size_t)n + 4 * (size_t)k + (size_t)cr * n + cr + 16;
+}
+template <typename T> struct NullOps {
+  const Ws<T>& w; T* Mb; int n, k;
+  __device__ inline T& G(int i, int l) const { return w.H[i + (size_t)l * w.ldh]; }
+  __device__ inline T& M(int i, int q) const { return Mb[i + (size_t)q * w.ldh]; }
+  // vec <- H_j vec for the reflector stored in column j of M (wave 0 only; vec has n entries in LDS)
+  __device__ inline void reflect(T* vec, int j, int lane) const {
+    const T tau = w.invd[j];
+    if (tau == (T)0) return;  // wave-uniform
+    T s = (T)0;
+    for (int i = j + lane; i < n; i += 64) s += (i == j ? (T)1 : M(i, j)) * vec[i];
+    s = wave_sum(s) * tau;
+    for (int i = j + lane; i < n; i += 64) vec[i] -= s * (i == j ? (T)1 : M(i, j));
+    wave_lds_fence();
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kMaxThreads) void nullspace_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ws<T> w;
+  const int n = a.n, k = a.k, m_r = a.m_r;
+  T* lp = reinterpret_cast<T*>(smem);
+  w.ldh = odd_ld(n);
+  w.H = lp; lp += (size_t)w.ldh * n;
+  T* const Mb = lp; lp += (size_t)w.ldh * k;
+  T* const u = lp; lp += n;     // particular solution
+  T* const g = lp; lp += n;     // c + G u, later Q^T (c + G u), later Q [0; y]
+  T* const pv = lp; lp += n;    // scratch of the two-sided update
+  T* const wv = lp; lp += n;
+  w.cvec = lp; lp += n;
+  w.beq = lp; lp += k;
+  T* const tau = lp; lp += k;   // Householder coefficients
+  T* const pidx = lp; lp += k;  // column permutation (stored as T)
+  T* const nrm = lp; lp += k;   // column norms
+  w.chunk_rows = chunk_rows_for(n, m_r, (int)sizeof(T));
+  w.Jc = lp; lp += (size_t)w.chunk_rows * n; w.rc = lp; lp += w.chunk_rows;
+  w.red = lp; lp += 16;
+  w.iflag = reinterpret_cast<int*>(lp);
+  w.invd = tau;                 // NullOps::reflect reads the coefficients through w.invd
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const NullOps<T> op{w, Mb, n, k};
+  const T eps = sizeof(T) == 8 ? (T)2.220446049250313e-16 : (T)1.1920929e-7f;
+  for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
+    __syncthreads();
+    const bool j_level = a.J != nullptr;
+    const T* Ap = (const T*)a.A + p * a.A_stride;
+    const T* bp = (const T*)a.b + p * a.b_stride;
+    if (tid < 8) w.iflag[tid] = 0;
+    load_qp(w, n, 0, j_level ? (const T*)nullptr : (const T*)a.G + p * a.G_stride, a.G_ld, j_level ? (const T*)nullptr : (const T*)a.c + p * a.c_stride,
+            (const T*)nullptr, 0, (const T*)nullptr, tid);
+    for (int idx = tid; idx < n * k; idx += kThreads) {                       // M = A_eq^T
+      const int i = idx / k, q = idx - i * k;
+      op.M(i, q) = Ap[q + (size_t)i * a.A_ld];
+    }
+    for (int q = tid; q < k; q += kThreads) w.beq[q] = bp[q];
+    if (j_level) {
+      const T lam = a.lambda_vec ? ((const T*)a.lambda_vec)[p * a.lambda_vec_stride] : (T)a.lambda;
+      accumulate_jtj(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
+    }
+    for (int l = wave; l < n; l += kWaves)   // selfadjointView<Lower>: mirror the lower triangle
+      for (int i = lane; i < l; i += 64) op.G(i, l) = op.G(l, i);
+    for (int q = tid; q < k; q += kThreads) { tau[q] = (T)0; pidx[q] = (T)q; }
+    __syncthreads();
+
+    // ---- Householder QR of M = A_eq^T with column pivoting (qp.cc:687)
+    T maxpivot = (T)0;
+    for (int j = 0; j < k; ++j) {
+      for (int q = j + wave; q < k; q += kWaves) {
+        T s = (T)0;
+        for (int i = j + lane; i < n; i += 64) { const T v = op.M(i, q); s += v * v; }
+        s = wave_sum(s);
+        if (lane == 0) nrm[q] = s;
+      }
+      __syncthreads();
+      int piv = j;
+      T big = nrm[j];
+      for (int q = j + 1; q < k; ++q) if (nrm[q] > big) { big = nrm[q]; piv = q; }   // uniform: every thread reads the same LDS values
+      if (big == (T)0) break;                     // the remaining columns are exactly zero: no further reflectors
+      __syncthreads();
+      if (piv != j) {
+        for (int i = tid; i < n; i += kThreads) { const T t = op.M(i, j); op.M(i, j) = op.M(i, piv); op.M(i, piv) = t; }
+        if (tid == 0) { const T t = pidx[j]; pidx[j] = pidx[piv]; pidx[piv] = t; }
+      }
+      __syncthreads();
+      // makeHouseholder on x = M(j.., j): beta = -sign(x0) |x|, tau = (beta - x0) / beta, essential = tail / (x0 - beta)
+      const T c0 = op.M(j, j);
+      const T tail2 = big - c0 * c0 > (T)0 ? big - c0 * c0 : (T)0;
+      T beta = c0, tj = (T)0;
+      if (tail2 > (T)0) {
+        T tsum = (T)0;                            // recomputed (not big - c0^2): no cancellation
+        for (int i = j + 1 + lane; i < n; i += 64) { const T v = op.M(i, j); tsum += v * v; }
+        tsum = wave_sum(tsum);
+        if (tsum > (T)0) {
+          beta = sqrtT(c0 * c0 + tsum);
+          if (c0 >= (T)0) beta = -beta;
+          tj = (beta - c0) / beta;
+        }
+      }
+      __syncthreads();
+      if (tj != (T)0) {
+        const T inv = (T)1 / (c0 - beta);
+        for (int i = j + 1 + tid; i < n; i += kThreads) op.M(i, j) *= inv;
+      } else {
+        for (int i = j + 1 + tid; i < n; i += kThreads) op.M(i, j) = (T)0;
+      }
+      if (tid == 0) { op.M(j, j) = beta; tau[j] = tj; }
+      __syncthreads();
+      if (tj != (T)0) {
+        for (int q = j + 1 + wave; q < k; q += kWaves) {   // remaining columns <- H_j columns
+          T s = (T)0;
+          for (int i = j + lane; i < n; i += 64) s += (i == j ? (T)1 : op.M(i, j)) * op.M(i, q);
+          s = wave_sum(s) * tj;
+          for (int i = j + lane; i < n; i += 64) op.M(i, q) -= s * (i == j ? (T)1 : op.M(i, j));
+        }
+      }
+      maxpivot = absT(beta) > maxpivot ? absT(beta) : maxpivot;
+      __syncthreads();
+    }
+    int rank = 0;
+    {
+      const T thr = maxpivot * eps * (T)(n < k ? n : k);
+      for (int j = 0; j < k && j < n; ++j) rank += (absT(op.M(j, j)) > thr) ? 1 : 0;
+    }
+
+    // ---- u = Q1 R1^-T P^T (-b_eq) (qp.cc:703-704); g = c + G u; g <- Q^T g
+    if (wave == 0) {
+      for (int i = lane; i < n; i += 64) u[i] = (T)0;
+      if (lane == 0) {
+        for (int i = 0; i < rank; ++i) {          // R1^T t = rhs, rhs_i = -b[pidx_i]
+          T acc = -w.beq[(int)pidx[i]];
+          for (int jj = 0; jj < i; ++jj) acc -= op.M(jj, i) * u[jj];
+          u[i] = acc / op.M(i, i);
+        }
+      }
+      wave_lds_fence();
+      for (int j = (k < n ? k : n) - 1; j >= 0; --j) op.reflect(u, j, lane);   // Q [t; 0] = H_0 ... H_{k-1} [t; 0]
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kThreads) {
+      T acc = w.cvec[i];
+      for (int l = 0; l < n; ++l) acc += op.G(i, l) * u[l];
+      g[i] = acc;
+    }
+    __syncthreads();
+    if (wave == 0)
+      for (int j = 0; j < k && j < n; ++j) op.reflect(g, j, lane);             // Q^T g = H_{k-1} ... H_0 g
+    __syncthreads();
+
+    // ---- G <- Q^T G Q (qp.cc:708), reflector by reflector on the block that still matters (indices >= j)
+    for (int j = 0; j < k && j < n; ++j) {
+      const T tj = tau[j];
+      if (tj == (T)0) continue;                                                // uniform
+      for (int i = j + tid; i < n; i += kThreads) {                            // p = tau G v
+        T acc = (T)0;
+        for (int l = j; l < n; ++l) acc += op.G(i, l) * (l == j ? (T)1 : op.M(l, j));
+        pv[i] = acc * tj;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        T s = (T)0;
+        for (int i = j + lane; i < n; i += 64) s += (i == j ? (T)1 : op.M(i, j)) * pv[i];
+        s = wave_sum(s) * (T)0.5 * tj;                                         // alpha = tau (v^T p) / 2
+        for (int i = j + lane; i < n; i += 64) wv[i] = pv[i] - s * (i == j ? (T)1 : op.M(i, j));
+      }
+      __syncthreads();
+      for (int l = j + wave; l < n; l += kWaves) {                             // G -= v w^T + w v^T
+        const T vl = l == j ? (T)1 : op.M(l, j), wl = wv[l];
+        for (int i = j + lane; i < n; i += 64) op.G(i, l) -= (i == j ? (T)1 : op.M(i, j)) * wl + wv[i] * vl;
+      }
+      __syncthreads();
+    }
+
+    // ---- LLT of G_reduced = G[rank.., rank..] (qp.cc:711-714), right-looking, lower triangle
+    const int q0 = rank, qn = n - rank;
+    int st = MO_STATUS_OK;
+    for (int kk = 0; kk < qn; ++kk) {
+      const T d = op.G(q0 + kk, q0 + kk);
+      if (!(d > (T)0)) { st = MO_STATUS_NOT_POSITIVE_DEFINITE; break; }        // uniform (every thread reads the same LDS word)
+      const T l = sqrtT(d), inv = (T)1 / l;
+      __syncthreads();
+      for (int i = kk + tid; i < qn; i += kThreads) op.G(q0 + i, q0 + kk) = i == kk ? l : op.G(q0 + i, q0 + kk) * inv;
+      __syncthreads();
+      for (int jj = kk + 1 + wave; jj < qn; jj += kWaves) {
+        const T wj = op.G(q0 + jj, q0 + kk);
+        for (int i = jj + lane; i < qn; i += 64) op.G(q0 + i, q0 + jj) -= op.G(q0 + i, q0 + kk) * wj;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- y = -(Q2^T (c + G u)) through L L^T (qp.cc:718-721); x = u + Q2 y (:725)
+    if (st == MO_STATUS_OK && wave == 0) {
+      T* y = g + q0;                                                           // rhs_y = -g[rank..] in place
+      for (int i = lane; i < qn; i += 64) y[i] = -y[i];
+      wave_lds_fence();
+      for (int kk = 0; kk < qn; ++kk) {                                        // forward, column oriented
+        const T yk = y[kk] / op.G(q0 + kk, q0 + kk);
+        wave_lds_fence();                                                      // every lane has read y[kk] before lane 0 replaces it
+        if (lane == 0) y[kk] = yk;
+        for (int i = kk + 1 + lane; i < qn; i += 64) y[i] -= op.G(q0 + i, q0 + kk) * yk;
+        wave_lds_fence();
+      }
+      for (int kk = qn - 1; kk >= 0; --kk) {                                   // backward with L^T
+        T s = (T)0;
+        for (int i = kk + 1 + lane; i < qn; i += 64) s += op.G(q0 + i, q0 + kk) * y[i];
+        s = wave_sum(s);
+        if (lane == 0) y[kk] = (y[kk] - s) / op.G(q0 + kk, q0 + kk);
+        wave_lds_fence();
+      }
+      for (int i = lane; i < q0; i += 64) g[i] = (T)0;                         // [0; y]
+      wave_lds_fence();
+      for (int j = (k < n ? k : n) - 1; j >= 0; --j) op.reflect(g, j, lane);
+    }
+    __syncthreads();
+    bool bad = false;
+    if (st == MO_STATUS_OK) {
+      for (int i = tid; i < n; i += kThreads) bad |= !finiteT(u[i] + g[i]);
+      if (bad) w.iflag[3] = 1;
+    }
+    __syncthreads();
+    if (st == MO_STATUS_OK && w.iflag[3]) st = MO_STATUS_NONFINITE;
+    T* xo = (T*)a.delta + p * a.delta_stride;
+    for (int i = tid; i < n; i += kThreads) xo[i] = st == MO_STATUS_OK ? u[i] + g[i] : nanT<T>();
+    if (a.status && tid == 0) a.status[p] = st;
+  }
+}
+
 }  // namespace
 
 size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
@@ -765,6 +1001,37 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
   if (dtype == MO_F64) { MO_DISPATCH_MODE(double) } else { MO_DISPATCH_MODE(float) }
 #undef MO_DISPATCH_MODE
 #undef MO_LAUNCH_GENERIC
+  return hipGetLastError();
+}
+
+size_t nullspace_lds_bytes(int n, int k, int m_r, int elem_size) {
+  const size_t e = elem_size == 8 ? nullspace_elems<double>(n, k, m_r) : nullspace_elems<float>(n, k, m_r);
+  return ((e * elem_size + 8 * sizeof(int)) + 15) & ~(size_t)15;
+}
+
+hipError_t launch_nullspace(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
+  const int elem = dtype == MO_F64 ? 8 : 4;
+  KernelArgs b = a;
+  b.m = 0;
+  const size_t lds = nullspace_lds_bytes(a.n, a.k, a.m_r, elem);
+  const int threads = (a.n + a.k <= 48) ? 64 : kMaxThreads;
+  const int max_per_cu = 32 / (threads / 64);
+  int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > max_per_cu) per_cu = max_per_cu;
+  long long grid = (long long)num_cus * per_cu;
+  if (grid > a.batch) grid = a.batch;
+  if (grid < 1) grid = 1;
+  hipError_t e;
+  if (dtype == MO_F64) {
+    e = hipFuncSetAttribute((const void*)nullspace_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((nullspace_kernel<double>), dim3((unsigned)grid), dim3(threads), lds, stream, b);
+  } else {
+    e = hipFuncSetAttribute((const void*)nullspace_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((nullspace_kernel<float>), dim3((unsigned)grid), dim3(threads), lds, stream, b);
+  }
   return hipGetLastError();
 }
 

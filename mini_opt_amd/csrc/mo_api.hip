@@ -486,19 +486,19 @@ int mo_nullspace_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, voi
   g_err[0] = 0;
   if (int rc = check_plan(plan)) return rc;
   if (plan->desc.k <= 0) return fail(MO_ERR_DIMENSION, "Problem must have at least one equality constraint");  // F_ASSERT_GT qp.cc:680
+  if (plan->desc.k > plan->desc.n) return fail(MO_ERR_DIMENSION, "k = %d equality rows for n = %d variables", plan->desc.k, plan->desc.n);
   if (!x_out || !termination) return fail(MO_ERR_INVALID_ARGUMENT, "x_out / termination is NULL");
   mo_plan tmp = *plan;
   tmp.desc.m = 0;  // no inequalities on this path
-  tmp.desc.flags |= MO_PLAN_FORCE_GENERIC;
   mo::KernelArgs a;
   if (int rc = fill_problem(&tmp, prob, batch, true, false, &a)) return rc;
-  a.mode = mo::MODE_STEP;
-  a.flags = MO_STEP_NO_INEQUALITIES | MO_STEP_NULLSPACE;
-  a.tau = 1.0;
+  if (batch == 0) return MO_OK;
   a.delta = x_out; a.delta_stride = x_stride;
-  a.status = termination;  // MO_STATUS_OK -> 0 SUCCESS; translated below
-  if (int rc = launch(&tmp, a, stream)) return rc;
-  // status word -> QPNullSpaceTerminationState: everything that is not OK means the reduced Hessian could not be factorised
+  a.status = termination;  // MO_STATUS_* first; translated to QPNullSpaceTerminationState below
+  const size_t need = mo::nullspace_lds_bytes(plan->desc.n, plan->desc.k, a.m_r, plan->elem);
+  if (need > 160 * 1024) return fail(MO_ERR_UNSUPPORTED, "the null-space solver keeps G and A_eq^T in LDS: %zu B needed (> 160 KiB)", need);
+  MO_HIP_CHECK(hipSetDevice(plan->desc.device));
+  MO_HIP_CHECK(mo::launch_nullspace(a, plan->desc.dtype, plan->num_cus, (hipStream_t)stream));
   mo::AuxArgs t;
   memset(&t, 0, sizeof(t));
   t.batch = batch; t.status = termination;
@@ -659,8 +659,20 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
     MO_HIP_CHECK(mo::launch_nonlinear_errors(ea, d.dtype, s));
     if (m > 0) MO_HIP_CHECK(mo::launch_shift_constraints(sa, d.dtype, s));
     // ComputeStepDirection (nonlinear.cc:216-247): the interior-point QP on device
-    if (int rc = qp_solve_impl(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, nullptr, lagrange, qp_status,
-                               si + mo::NLS_SI_TERM, mo::NLS_SI, stream)) return rc;  // terminated problems are skipped
+    if (m == 0 && k > 0 && k <= n && mo::nullspace_lds_bytes(n, k, d.m_r, plan->elem) <= 160 * 1024) {
+      // equality constraints only: QPNullSpaceSolver (nonlinear.cc:83-86, 249-258) -- singular G = J^T J is fine as long as
+      // the reduced Hessian is positive definite; NOT_POSITIVE_DEFINITE ends the problem with QP_INDEFINITE (:103-105)
+      mo_plan tmp = *plan;
+      mo::KernelArgs ka;
+      if (int rc = fill_problem(&tmp, &qp, batch, true, false, &ka)) return rc;
+      ka.delta = qp_vars; ka.delta_stride = Vs; ka.status = qp_status;
+      MO_HIP_CHECK(hipMemsetAsync(qp_term, 0, sizeof(int) * (size_t)batch, s));
+      MO_HIP_CHECK(hipMemsetAsync(qp_nit, 0, sizeof(int) * (size_t)batch, s));
+      MO_HIP_CHECK(mo::launch_nullspace(ka, d.dtype, plan->num_cus, s));
+    } else if (int rc = qp_solve_impl(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, nullptr, lagrange, qp_status,
+                                      si + mo::NLS_SI_TERM, mo::NLS_SI, stream)) {
+      return rc;  // terminated problems are skipped
+    }
     MO_HIP_CHECK(mo::launch_cost_derivative(da, d.dtype, s));
     MO_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
     MO_HIP_CHECK(mo::launch_nls_begin_search(na, s));

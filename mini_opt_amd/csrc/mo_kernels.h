@@ -7,9 +7,6 @@
 
 namespace mo {
 
-// internal step flag (beside the public MO_STEP_*): mo_nullspace_solve -- state = 0, inertia check, x block only
-#define MO_STEP_NULLSPACE 0x100u
-
 enum Mode : int {
   MODE_LINEARIZE = 0,  // nonlinear.cc:182-189 (J^T J, J^T r)
   MODE_RESIDUAL = 1,   // qp.cc:391-437
@@ -63,6 +60,9 @@ struct KernelArgs {
 // shape-generic LDS kernel (any n,k,m,m_r that fits LDS), kkt_generic.hip
 size_t generic_lds_bytes(const KernelArgs& a, int elem_size);
 hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
+// QPNullSpaceSolver::Solve (qp.cc:679-729): pivoted Householder QR of A_eq^T, reduced Hessian, LLT; x -> a.delta, status -> a.status
+hipError_t launch_nullspace(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
+size_t nullspace_lds_bytes(int n, int k, int m_r, int elem_size);
 
 // fused single-wave MFMA kernels for fixed shapes, kkt_fused.hip.  Returns false if (shape, layout) is unsupported.
 bool fused_supported(const KernelArgs& a, int dtype);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Error of the Newton direction on hard inputs (tests/stress_cases.py) against a long-double solve of the unreduced system:
+"""Error of the Newton direction on hard inputs (tests/stress_cases.py; run as `python tests/stress_table.py` on the GPU box) against a long-double solve of the unreduced system:
 the device kernels (fused step = x+ form, generic step, fused Iterate = residual form) beside the oracle's two variants (reference
 arithmetic with Eigen's explicit inverse / direct solve).  Prints one row per case; DESIGN.md section 2 quotes the table."""
 import json

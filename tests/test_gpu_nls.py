@@ -218,6 +218,65 @@ def test_null_space_solver():
     np.testing.assert_allclose(sJ.variables().cpu().numpy()[good], x[good], rtol=1e-9, atol=1e-11)
 
 
+def _nullspace(G, c, A, b, dt=torch.float64):
+    """Batch-1 QPNullSpaceSolver call; returns (termination, x)."""
+    n, k = G.shape[0], A.shape[0]
+    s = Q.QPNullSpaceSolver()
+    term = s.Solve(Q.BatchedQP(n=n, k=k, G=T(np.tril(G).T[None], dt), c=T(c[None], dt), A_eq=T(A.T[None], dt), b_eq=T(b[None], dt)))
+    return int(term[0]), s.variables().double().cpu().numpy()[0]
+
+
+def test_null_space_solver_on_singular_and_indefinite_hessians():
+    """The inputs on which a KKT LDL^T in natural order cannot stand in for qp.cc:687-727: what decides SUCCESS is the reduced Hessian
+    Q2^T G Q2 alone (LLT, qp.cc:711-714), not G."""
+    # G = diag(1, 0) is singular, A = [0 1] fixes the direction G does not see: Z^T G Z = 1 > 0
+    term, x = _nullspace(np.diag([1.0, 0.0]), np.array([-2.0, 5.0]), np.array([[0.0, 1.0]]), np.array([-3.0]))
+    assert term == Q.QPNullSpaceSolver.SUCCESS
+    np.testing.assert_allclose(x, [2.0, 3.0], atol=1e-14)
+    # the leading entry of G is ZERO (an un-pivoted elimination stops at its first pivot); the null space is span{(1, -1, 0), e3}
+    G = np.array([[0.0, 0.0, 0.0], [0.0, 2.0, 0.0], [0.0, 0.0, 1.0]])
+    term, x = _nullspace(G, np.array([1.0, 1.0, 1.0]), np.array([[1.0, 1.0, 0.0]]), np.array([-1.0]))
+    ok, xr = N.null_space_solve(N.QPData(np.tril(G), np.array([1.0, 1.0, 1.0]), np.array([[1.0, 1.0, 0.0]]), np.array([-1.0]), []))
+    assert ok and term == Q.QPNullSpaceSolver.SUCCESS
+    np.testing.assert_allclose(x, xr, atol=1e-14)
+    # G indefinite (eigenvalue -1 along e1) but positive definite on null(A) = {x1 = 0}
+    G = np.diag([-1.0, 2.0, 3.0])
+    term, x = _nullspace(G, np.array([1.0, -4.0, 6.0]), np.array([[1.0, 0.0, 0.0]]), np.array([-0.5]))
+    assert term == Q.QPNullSpaceSolver.SUCCESS
+    np.testing.assert_allclose(x, [0.5, 2.0, -2.0], atol=1e-14)
+    # ... and the same G with the equality on x2 instead leaves the negative direction in the null space
+    term, x = _nullspace(G, np.array([1.0, -4.0, 6.0]), np.array([[0.0, 1.0, 0.0]]), np.array([-0.5]))
+    assert term == Q.QPNullSpaceSolver.NOT_POSITIVE_DEFINITE and np.all(np.isnan(x))
+    # a duplicated equality row: rank 1 of 2 (Eigen's QR.rank(), qp.cc:697); the consistent reading (oracle) succeeds
+    G = np.diag([1.0, 2.0, 4.0])
+    A = np.array([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]]); b = np.array([-3.0, -3.0])
+    ok, xr = N.null_space_solve(N.QPData(np.tril(G), np.array([0.5, -1.0, 2.0]), A, b, []))
+    term, x = _nullspace(G, np.array([0.5, -1.0, 2.0]), A, b)
+    assert ok and term == Q.QPNullSpaceSolver.SUCCESS
+    np.testing.assert_allclose(x, xr, atol=1e-13)
+    np.testing.assert_allclose(A @ x + b, 0, atol=1e-13)
+
+
+@pytest.mark.parametrize("n,k,m_r", [(64, 8, 40), (128, 12, 120), (33, 7, 20), (100, 30, 71), (6, 6, 3), (24, 5, 40)])
+def test_null_space_solver_with_rank_deficient_cost(n, k, m_r):
+    """J-level input with lambda = 0 and fewer residual rows than variables: G = J^T J is singular, the reduced Hessian is positive
+    definite iff m_r + k >= n (general position).  Device vs the oracle's QR / Cholesky restatement, problem by problem."""
+    rng = np.random.default_rng(n * 1000 + k)
+    B = 9
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, k, n)); b = rng.uniform(-1, 1, (B, k))
+    s = Q.QPNullSpaceSolver()
+    term = s.Solve(Q.BatchedQP(n=n, k=k, J=T(J), r=T(r), lam=0.0, A_eq=T(A.transpose(0, 2, 1)), b_eq=T(b))).cpu().numpy()
+    x = s.variables().cpu().numpy()
+    for p in range(B):
+        G = J[p].T @ J[p]
+        ok, xr = N.null_space_solve(N.QPData(np.tril(G), J[p].T @ r[p], A[p], b[p], []))
+        assert ok == (m_r + k >= n) and (term[p] == 0) == ok, (p, ok, term[p])
+        if ok:
+            np.testing.assert_allclose(x[p], xr, rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(A[p] @ x[p] + b[p], 0, atol=1e-10)
+
+
 def test_device_residual_families_match_the_torch_definitions():
     """mo_residual_eval (row f2): values and dense Jacobians of the four families against the torch / numpy definitions of the
     reference's test residuals."""
