@@ -167,7 +167,8 @@ def null_space_solve(qp: QPData):
     k, n = A.shape
     Q, R, P = scipy.linalg.qr(A.T, mode="full", pivoting=True)
     diag = np.abs(np.diag(R[:k, :k]))
-    rank = int(np.sum(diag > diag.max() * max(n, k) * np.finfo(float).eps)) if k else 0   # Eigen's default threshold
+    # Eigen's default threshold (ColPivHouseholderQR::threshold(): epsilon * diagonalSize(), applied to the largest pivot)
+    rank = int(np.sum(diag > diag.max() * min(n, k) * np.finfo(float).eps)) if k else 0
     Q1, Q2 = Q[:, :rank], Q[:, rank:]
     rhs = (-qp.b_eq)[P]
     u = Q1 @ scipy.linalg.solve_triangular(R[:rank, :rank].T, rhs[:rank], lower=True)
@@ -196,11 +197,15 @@ class IterationLog:
 
 
 class ConstrainedNonlinearLeastSquares:
-    """nonlinear.cc:20-158 (default retraction x + alpha dx)."""
+    """nonlinear.cc:20-158.  `retraction(x, dx, alpha) -> candidate` is the reference's custom Retraction (nonlinear.hpp:127,
+    nonlinear.cc:160-168; default x + alpha dx); `user_exit_callback(log) -> bool` is SetUserExitCallback (nonlinear.hpp:157,
+    nonlinear.cc:142-149): returning False ends the solve with USER_CALLBACK unless the iteration terminates anyway."""
 
-    def __init__(self, problem: Problem):
+    def __init__(self, problem: Problem, retraction=None, user_exit_callback=None):
         self.p = problem
         self.variables = np.zeros(problem.dimension)
+        self.retraction = retraction
+        self.user_exit_callback = user_exit_callback
 
     def compute_step_direction(self, qp: QPData, params: Params):
         """nonlinear.cc:216-258.  Returns (dx, lagrange_linf | None, indefinite, n_qp_iterations)."""
@@ -245,7 +250,10 @@ class ConstrainedNonlinearLeastSquares:
                     alpha = new_alpha
             elif it > 0:
                 alpha = alpha * params.armijo_search_tau
-            candidate = self.variables + dx * alpha        # RetractCandidateVars, :160-168
+            if self.retraction is not None:                # RetractCandidateVars, :160-168
+                candidate = np.asarray(self.retraction(self.variables.copy(), dx, alpha), float)
+            else:
+                candidate = self.variables + dx * alpha
             e = evaluate_nonlinear_errors(self.p, candidate)
             steps.append((alpha, e))
             if e.invalid():
@@ -303,6 +311,10 @@ class ConstrainedNonlinearLeastSquares:
                 if lam > params.max_lambda:
                     exit_state = MAX_LAMBDA
             logs.append(IterationLog(old_lam, errors_pre, d_f, d_eq, penalty, step_result, steps, n_qp, state))
+            if self.user_exit_callback is not None:        # :142-149
+                proceed = self.user_exit_callback(logs[-1])
+                if exit_state is None and not proceed:
+                    return USER_CALLBACK, logs
             if exit_state is not None:
                 return exit_state, logs
         return MAX_ITERATIONS, logs

@@ -177,3 +177,110 @@ def nullspace_kats():
               expected=[(1, -3.656565656565657, 1e-14), (3, -4.838383838383838, 1e-14), (0, -0.707724112814252, 1e-13),
                         (2, 0.0247370254266801, 1e-13)])
     return [k1, k2]
+
+
+# ---- kinematic-chain robots, nonlinear_test.cc:828-1136 (chains: test/transform_chains.cc) -----------------------------------------
+# A problem is data: chains of links (base euler-xyz rotation, translation, 6 activity flags, the index in x of every active parameter)
+# and residual rows that are affine in the effector translations of the chains and in x:
+#   row = const + sum_i lin[i] x_i + sum_c (wx, wy, wz) . t_effector(chain c)
+# Both the numpy evaluator below (oracle side, on oracle/chain_oracle.py) and the device family MO_RESIDUAL_ACTUATOR_CHAIN consume it.
+def chain_link(translation, mask=(0, 0, 0, 0, 0, 0), params=(), rotation_xyz=(0.0, 0.0, 0.0)):
+    assert sum(1 for v in mask if v) == len(params)
+    return dict(rotation_xyz=tuple(rotation_xyz), translation=tuple(translation), mask=tuple(mask), params=tuple(params))
+
+
+def chain_row(const=0.0, lin=None, terms=()):
+    return dict(const=float(const), lin=dict(lin or {}), terms=[(int(c), float(wx), float(wy), float(wz)) for c, wx, wy, wz in terms])
+
+
+Z = (0, 0, 1, 0, 0, 0)   # only the z angle of the link is optimised (nonlinear_test.cc:833, 967)
+
+# TestTwoAngleActuatorChain, nonlinear_test.cc:828-964: two revolute joints, effector 0.4 beyond the second; cost: y -> 0.6, equality: x = 0.45
+TWO_ANGLE = dict(
+    n=2,
+    chains=[[chain_link((0.0, 0.0, 0.0), Z, (0,)), chain_link((0.4, 0.0, 0.0), Z, (1,)), chain_link((0.4, 0.0, 0.0))]],
+    cost_rows=[chain_row(-0.6, terms=[(0, 0, 1, 0)])],
+    eq_rows=[chain_row(-0.45, terms=[(0, 1, 0, 0)])],
+    target_xy=(0.45, 0.6),
+    inequalities_stage2=[(1, 1.0, 0.0), (1, -1.0, math.pi)],     # Var(1) >= 0, Var(1) <= pi, :917-918
+    params=dict(max_iterations=50, max_qp_iterations=1, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-10, absolute_exit_tol=1e-9,
+                termination_kkt_tolerance=1e-6, max_line_search_iterations=10, equality_penalty_initial=0.01, line_search_strategy=0,
+                lambda_failure_init=0.001, armijo_search_tau=0.5, lambda_initial=0.001, min_lambda=1e-9))   # :881-901 (ARMIJO_BACKTRACK = 0)
+
+
+def two_angle_guesses(stage):
+    g = []
+    t0 = 0.1
+    while t0 <= math.pi / 2:                                   # :904-909 / :920-925
+        t1 = -math.pi / 3 if stage == 1 else 1e-3
+        hi = math.pi / 3 if stage == 1 else math.pi / 2 - 1e-3
+        while t1 <= hi:
+            g.append((t0, t1))
+            t1 += 0.1
+        t0 += 0.1
+    return g
+
+
+# TestDualActuatorBalancing, nonlinear_test.cc:966-1136: body angle x0 shared by two legs; rear leg x1, x2; front leg x3, x4
+_ORIGIN = (0.0, 0.4, 0.0)
+DUAL = dict(
+    n=5,
+    chains=[[chain_link(_ORIGIN, Z, (0,)), chain_link((0.0, 0.0, 0.0), Z, (1,)), chain_link((0.3, 0.0, 0.0), Z, (2,)), chain_link((0.3, 0.0, 0.0))],      # rear, :981-986
+            [chain_link(_ORIGIN, Z, (0,)), chain_link((0.25, 0.0, 0.0), Z, (3,)), chain_link((0.3, 0.0, 0.0), Z, (4,)), chain_link((0.3, 0.0, 0.0))]],    # front, :973-978
+    # costs: 0.1 * body angle (:992-1001); moments mu1 (yr - yf) + (xr - 0.15) + (xf - 0.15) mu1 / mu2 with mu1 = 1, mu2 = 2 (:1035-1067)
+    cost_rows=[chain_row(0.0, lin={0: 0.1}), chain_row(-0.15 - 0.15 * 0.5, terms=[(0, 1.0, 1.0, 0.0), (1, 0.5, -1.0, 0.0)])],
+    eq_rows=[chain_row(0.0, terms=[(0, 0, 1, 0)]), chain_row(-0.05, terms=[(1, 0, 1, 0)])],                  # feet on the floor, :1005-1031
+    inequalities=[(2, 1.0, 0.0), (2, -1.0, math.pi)],                                                        # knee of the rear leg, :1073-1074
+    guesses=[(math.pi / 6, -math.pi / 2, math.pi / 6, -math.pi / 2, math.pi / 4), (-math.pi / 4, -math.pi / 4, math.pi / 6, -math.pi / 3, -math.pi / 4),
+             (-math.pi / 3, -math.pi / 2, 0.001, -math.pi / 2, 0.0)],                                        # :1105-1113
+    params=dict(max_iterations=100, max_qp_iterations=5, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-10, absolute_exit_tol=1e-8,
+                termination_kkt_tolerance=1e-6, max_line_search_iterations=5, line_search_strategy=0, lambda_failure_init=0.01,
+                armijo_search_tau=0.5, lambda_initial=0.001, min_lambda=1e-9))                               # :1087-1102
+
+
+def _chains_np(spec):
+    from oracle import chain_oracle as CH
+    out = []
+    for links in spec["chains"]:
+        chain = CH.ActuatorChain([CH.ActuatorLink(CH.Pose(CH.so3_from_euler_xyz(l["rotation_xyz"])[0], np.array(l["translation"], float)), l["mask"])
+                                  for l in links])
+        out.append((chain, [i for l in links for i in l["params"]]))
+    return out
+
+
+def chain_rows_np(spec, rows):
+    """numpy residual function (x, want_J) -> (r, J) of `rows` of a chain problem, on the oracle's ActuatorChain."""
+    chains = _chains_np(spec)
+    n = spec["n"]
+
+    def fn(x, want_J):
+        x = np.asarray(x, float)
+        for chain, idx in chains:
+            chain.update(x[idx])
+        r = np.zeros(len(rows))
+        J = np.zeros((len(rows), n)) if want_J else None
+        for q, row in enumerate(rows):
+            r[q] = row["const"] + sum(cf * x[i] for i, cf in row["lin"].items())
+            if want_J:
+                for i, cf in row["lin"].items():
+                    J[q, i] += cf
+            for c, wx, wy, wz in row["terms"]:
+                chain, idx = chains[c]
+                w = np.array([wx, wy, wz])
+                r[q] += float(w @ chain.translation())
+                if want_J:
+                    np.add.at(J[q], idx, w @ chain.translation_D_params)
+        return r, J
+    return fn
+
+
+def chain_effector_np(spec, chain_id, x):
+    chain, idx = _chains_np(spec)[chain_id]
+    chain.update(np.asarray(x, float)[idx])
+    return chain.translation()
+
+
+def mod_pi_retraction_np(x, dx, alpha):
+    """The reference's custom Retraction on these problems (nonlinear_test.cc:874-880, 1077-1084): angles wrapped to [-pi, pi)."""
+    from oracle import chain_oracle as CH
+    return np.array([CH.mod_pi(v) for v in (x + dx * alpha)])

@@ -122,3 +122,67 @@ def test_null_space_solver_kats():
     G = np.diag([1.0, -2.0, 3.0])
     ok, _ = N.null_space_solve(N.QPData(G, np.zeros(3), np.array([[1.0, 0.0, 0.0]]), np.array([0.5]), []))
     assert not ok
+
+
+# ---- kinematic-chain robots, nonlinear_test.cc:828-1136 (problem data in tests/nls_problems.py, chains in oracle/chain_oracle.py)
+def test_chain_residual_derivatives():
+    """TestResidualFunctionDerivative on the chain residuals (nonlinear_test.cc:861-862, 1001, 1017, 1029, 1068-1069)."""
+    for spec, rows, x in ((P.TWO_ANGLE, P.TWO_ANGLE["cost_rows"], [-0.5, 0.4]), (P.TWO_ANGLE, P.TWO_ANGLE["eq_rows"], [0.3, -0.6]),
+                          (P.DUAL, P.DUAL["cost_rows"], [0.22, -0.3, 0.45, 0.6, -0.1]), (P.DUAL, P.DUAL["eq_rows"], [0.4, 0.2221, -0.8, -0.4, 0.5])):
+        fn = P.chain_rows_np(spec, rows)
+        x = np.array(x)
+        _, J = fn(x, True)
+        h = 1e-6
+        Jn = np.stack([(fn(x + h * e, False)[0] - fn(x - h * e, False)[0]) / (2 * h) for e in np.eye(len(x))], axis=1)
+        np.testing.assert_allclose(J, Jn, atol=1e-8)
+
+
+def _steps(logs):
+    return sum(len(l.steps) for l in logs)
+
+
+def test_two_angle_actuator_chain():
+    """TestTwoAngleActuatorChain, nonlinear_test.cc:828-964: every initial guess of both grids reaches the target effector position
+    (5e-5 with the equality alone -- the null-space QP path --, 1e-3 and < 100 line-search steps with the box on angle 1)."""
+    spec = P.TWO_ANGLE
+    prm = dict(spec["params"])
+    prob = N.Problem(2, P.chain_rows_np(spec, spec["cost_rows"]), equality=P.chain_rows_np(spec, spec["eq_rows"]))
+    for guess in P.two_angle_guesses(1):
+        nls = N.ConstrainedNonlinearLeastSquares(prob, retraction=P.mod_pi_retraction_np)
+        nls.solve(N.Params(**prm), guess)
+        np.testing.assert_allclose(P.chain_effector_np(spec, 0, nls.variables)[:2], spec["target_xy"], atol=5e-5, err_msg=str(guess))
+    prob2 = N.Problem(2, prob.cost, equality=prob.equality, inequality_constraints=spec["inequalities_stage2"])
+    prm["max_qp_iterations"] = 10                                                   # :928
+    for guess in P.two_angle_guesses(2):
+        nls = N.ConstrainedNonlinearLeastSquares(prob2, retraction=P.mod_pi_retraction_np)
+        _, logs = nls.solve(N.Params(**prm), guess)
+        np.testing.assert_allclose(P.chain_effector_np(spec, 0, nls.variables)[:2], spec["target_xy"], atol=1e-3, err_msg=str(guess))
+        assert _steps(logs) < 100
+
+
+def test_dual_actuator_balancing():
+    """TestDualActuatorBalancing, nonlinear_test.cc:966-1136: SATISFIED_ABSOLUTE_TOL from all three guesses, every residual's quadratic
+    error below 1e-8, fewer than 36 line-search steps."""
+    spec = P.DUAL
+    cost, eq = P.chain_rows_np(spec, spec["cost_rows"]), P.chain_rows_np(spec, spec["eq_rows"])
+    prob = N.Problem(5, cost, equality=eq, inequality_constraints=spec["inequalities"])
+    for guess in spec["guesses"]:
+        nls = N.ConstrainedNonlinearLeastSquares(prob, retraction=P.mod_pi_retraction_np)
+        term, logs = nls.solve(N.Params(**spec["params"]), guess)
+        assert term == N.SATISFIED_ABSOLUTE_TOL, (guess, term)
+        for fn in (cost, eq):
+            r, _ = fn(nls.variables, False)
+            assert np.all(0.5 * r * r <= 1e-8), (guess, r)                          # Residual::QuadraticError per residual, :1123-1128
+        assert _steps(logs) < 36
+
+
+def test_user_exit_callback():
+    """SetUserExitCallback (nonlinear.hpp:157, nonlinear.cc:142-149): returning false after the second iteration ends the solve with
+    USER_CALLBACK; a callback that always proceeds changes nothing."""
+    seen = []
+    nls = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.rosenbrock_np), user_exit_callback=lambda log: (seen.append(log), len(seen) < 2)[1])
+    term, logs = nls.solve(N.Params(max_iterations=10, max_qp_iterations=1), (-5.0, -3.0))
+    assert term == N.USER_CALLBACK and len(logs) == 2
+    nls2 = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.rosenbrock_np), user_exit_callback=lambda log: True)
+    term2, _ = nls2.solve(N.Params(max_iterations=5, max_qp_iterations=1), (-5.0, -3.0))
+    assert term2 == N.SATISFIED_ABSOLUTE_TOL
