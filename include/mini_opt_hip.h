@@ -243,7 +243,13 @@ typedef enum { MO_NLS_MAX_ITERATIONS = 0, MO_NLS_SATISFIED_ABSOLUTE_TOL = 1, MO_
 typedef enum { MO_LS_SUCCESS = 0, MO_LS_MAX_ITERATIONS = 1, MO_LS_FIRST_ORDER_SATISFIED = 2, MO_LS_POSITIVE_DERIVATIVE = 3,
                MO_LS_FAILURE_NON_FINITE_COST = 4, MO_LS_FAILURE_INVALID_ALPHA = 5 } mo_step_result; /* StepSizeSelectionResult, structs.hpp:215-228 */
 typedef enum { MO_ARMIJO_BACKTRACK = 0, MO_POLYNOMIAL_APPROXIMATION = 1 } mo_line_search;      /* structs.hpp:148-153 */
-typedef enum { MO_NLS_EVAL_LINEARIZE = 0, MO_NLS_EVAL_ERRORS = 1 } mo_nls_eval;
+typedef enum { MO_NLS_EVAL_LINEARIZE = 0, MO_NLS_EVAL_ERRORS = 1, MO_NLS_EVAL_RETRACT = 2, MO_NLS_EVAL_ITERATION_DONE = 3 } mo_nls_eval;
+/* Retraction (nonlinear.hpp:127, RetractCandidateVars nonlinear.cc:160-168): how a trial point is formed from vars, the step dx and
+ * the step length alpha.  EUCLIDEAN = the reference's default x + alpha dx; WRAP_PI = every variable wrapped into [-pi, pi) afterwards
+ * (math::ModPi: the custom Retraction of the reference's robot tests, nonlinear_test.cc:874-880, 1077-1084); CALLBACK = the caller's
+ * own: before each evaluation the library writes dx to mo_nls_problem.step and alpha to mo_nls_problem.step_alpha and calls
+ * eval(user, MO_NLS_EVAL_RETRACT, stream), which must enqueue work that fills `candidate` for all problems. */
+typedef enum { MO_RETRACT_EUCLIDEAN = 0, MO_RETRACT_WRAP_PI = 1, MO_RETRACT_CALLBACK = 2 } mo_retraction;
 
 /* ConstrainedNonlinearLeastSquares::Params (nonlinear.hpp:64-124); mo_default_nls_params fills the reference defaults. */
 typedef struct {
@@ -265,6 +271,8 @@ typedef struct {
   double lambda_decrease_on_restore;
   double max_lambda;
   double min_lambda;
+  int32_t retraction;                  /* mo_retraction */
+  int32_t reserved;
 } mo_nls_params;
 
 /* Device buffers of one batch (all owned by the caller; shapes per problem, strides in elements, plan dims n, k, m, m_r). */
@@ -278,6 +286,12 @@ typedef struct {
   void* r_cand;    int64_t r_cand_stride;    /* m_r, filled by eval(ERRORS) */
   void* r_eq_cand; int64_t r_eq_cand_stride; /* k */
   const int32_t* cons_var; const void* cons_a; const void* cons_b; int64_t cons_stride; /* m: Problem::inequality_constraints */
+  void* step; int64_t step_stride;   /* n : dx of the current outer iteration (written only with MO_RETRACT_CALLBACK) */
+  void* step_alpha;                  /* 1 per problem: the alpha of the trial point to form (MO_RETRACT_CALLBACK) */
+  int32_t* user_exit;                /* NULL, or [batch] flags for SetUserExitCallback (nonlinear.hpp:157, nonlinear.cc:142-149): after every
+                                        outer iteration eval(user, MO_NLS_EVAL_ITERATION_DONE, stream) is called (the iteration's record is in
+                                        `iterations`, the state in `vars`); a problem whose flag it sets non-zero ends with
+                                        MO_NLS_USER_CALLBACK unless that iteration terminated it anyway.  Zeroed by mo_nls_solve on entry. */
 } mo_nls_problem;
 
 typedef int (*mo_nls_eval_fn)(void* user, int32_t what, void* stream);  /* non-zero return aborts mo_nls_solve with MO_ERR_CALLBACK */
@@ -302,9 +316,17 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* prob, int64_t batch, const
  *   HIMMELBLAU     n = 2, rows = 2: x^2 + y - 11, x + y^2 - 7                                  (nonlinear_test.cc:578-593)
  *   SPHERE         rows = n: r = x                                                             (nonlinear_test.cc:722-730)
  *   PRODUCT_PAIRS  rows <= n / 2: r_q = x_2q x_2q+1 - params[q]  (params: `rows` device scalars) (nonlinear_test.cc:737-743)
+ *   ACTUATOR_CHAIN the kinematic chains of the reference's robot tests (test/transform_chains.cc:23-82 ComputeChain, :125-158
+ *                  ActuatorLink::Compute, :165-244 ActuatorChain::Update; used at nonlinear_test.cc:828-1136): every row is affine in
+ *                  the effector translations of up to 4 chains and in x,  r_q = const_q + sum_i lin_qi x_i + sum_c w_qc . t_c(x),
+ *                  with the Jacobian through translation_D_params.  params (device scalars of the plan's dtype, integers stored as
+ *                  scalars):  [C,  then per chain: L, then per link 12 values: euler-xyz rotation (R = Rx Ry Rz), translation, and for
+ *                  each of the 6 degrees of freedom (rx, ry, rz, tx, ty, tz) the index in x of the parameter that replaces it or -1;
+ *                  then per row: const, n_lin, n_lin x (index, coefficient), n_terms, n_terms x (chain, wx, wy, wz)].  L <= 8.
  * r [batch][rows]; J (NULL = values only) dense rows x n per problem, row-major (cost stacks) or column-major (equality stacks,
  * = QP::A_eq), zeros written. */
-typedef enum { MO_RESIDUAL_ROSENBROCK = 0, MO_RESIDUAL_HIMMELBLAU = 1, MO_RESIDUAL_SPHERE = 2, MO_RESIDUAL_PRODUCT_PAIRS = 3 } mo_residual_family;
+typedef enum { MO_RESIDUAL_ROSENBROCK = 0, MO_RESIDUAL_HIMMELBLAU = 1, MO_RESIDUAL_SPHERE = 2, MO_RESIDUAL_PRODUCT_PAIRS = 3,
+               MO_RESIDUAL_ACTUATOR_CHAIN = 4 } mo_residual_family;
 int mo_residual_eval(mo_plan* plan, int32_t family, int32_t rows, const void* params, const void* x, int64_t x_stride,
                      int64_t batch, void* r, int64_t r_stride, void* J, int64_t J_stride, int32_t J_ld, int32_t J_layout,
                      void* stream);

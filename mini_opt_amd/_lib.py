@@ -61,7 +61,7 @@ class NlsParams(C.Structure):
                 ("equality_penalty_initial", C.c_double), ("equality_penalty_scale_factor", C.c_double),
                 ("equality_penalty_rho", C.c_double), ("lambda_initial", C.c_double), ("lambda_failure_init", C.c_double),
                 ("lambda_decrease_on_success", C.c_double), ("lambda_decrease_on_restore", C.c_double),
-                ("max_lambda", C.c_double), ("min_lambda", C.c_double)]
+                ("max_lambda", C.c_double), ("min_lambda", C.c_double), ("retraction", C.c_int32), ("reserved", C.c_int32)]
 
 
 class NlsProblem(C.Structure):
@@ -71,13 +71,15 @@ class NlsProblem(C.Structure):
                 ("J_eq", C.c_void_p), ("J_eq_stride", C.c_int64), ("J_eq_ld", C.c_int32), ("reserved0", C.c_int32),
                 ("r_eq", C.c_void_p), ("r_eq_stride", C.c_int64),
                 ("r_cand", C.c_void_p), ("r_cand_stride", C.c_int64), ("r_eq_cand", C.c_void_p), ("r_eq_cand_stride", C.c_int64),
-                ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64)]
+                ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64),
+                ("step", C.c_void_p), ("step_stride", C.c_int64), ("step_alpha", C.c_void_p), ("user_exit", C.c_void_p)]
 
 
 NLS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
-MO_NLS_EVAL_LINEARIZE, MO_NLS_EVAL_ERRORS = 0, 1
+MO_NLS_EVAL_LINEARIZE, MO_NLS_EVAL_ERRORS, MO_NLS_EVAL_RETRACT, MO_NLS_EVAL_ITERATION_DONE = 0, 1, 2, 3
+MO_RETRACT_EUCLIDEAN, MO_RETRACT_WRAP_PI, MO_RETRACT_CALLBACK = 0, 1, 2
 MO_NLS_ITER_HEADER = 12
-MO_RESIDUAL_ROSENBROCK, MO_RESIDUAL_HIMMELBLAU, MO_RESIDUAL_SPHERE, MO_RESIDUAL_PRODUCT_PAIRS = range(4)
+MO_RESIDUAL_ROSENBROCK, MO_RESIDUAL_HIMMELBLAU, MO_RESIDUAL_SPHERE, MO_RESIDUAL_PRODUCT_PAIRS, MO_RESIDUAL_ACTUATOR_CHAIN = range(5)
 
 
 def build(force: bool = False) -> str:

@@ -527,6 +527,7 @@ void mo_default_nls_params(mo_nls_params* p) {
   p->lambda_decrease_on_restore = 0.8;
   p->max_lambda = 1.0;
   p->min_lambda = 0.0;
+  p->retraction = MO_RETRACT_EUCLIDEAN;
 }
 
 
@@ -558,6 +559,9 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
   if (!(prm->lambda_decrease_on_restore >= 0) || !(prm->lambda_decrease_on_restore < 1.0)) return fail(MO_ERR_INVALID_ARGUMENT, "lambda_decrease_on_restore must be in [0, 1)");
   if (prm->line_search_strategy != MO_ARMIJO_BACKTRACK && prm->line_search_strategy != MO_POLYNOMIAL_APPROXIMATION)
     return fail(MO_ERR_INVALID_ARGUMENT, "bad line_search_strategy");
+  if (prm->retraction < MO_RETRACT_EUCLIDEAN || prm->retraction > MO_RETRACT_CALLBACK) return fail(MO_ERR_INVALID_ARGUMENT, "bad retraction");
+  if (prm->retraction == MO_RETRACT_CALLBACK && (!np->step || !np->step_alpha))
+    return fail(MO_ERR_INVALID_ARGUMENT, "MO_RETRACT_CALLBACK needs the step / step_alpha buffers");
   if (!np->vars || !np->candidate || !np->J || !np->r || !np->r_cand) return fail(MO_ERR_INVALID_ARGUMENT, "vars / candidate / J / r / r_cand is NULL");
   if (d.k > 0 && (!np->J_eq || !np->r_eq || !np->r_eq_cand)) return fail(MO_ERR_DIMENSION, "k = %d but J_eq / r_eq / r_eq_cand is NULL", d.k);
   if (d.m > 0 && (!np->cons_var || !np->cons_a || !np->cons_b)) return fail(MO_ERR_INVALID_ARGUMENT, "m = %d but constraint arrays are NULL", d.m);
@@ -610,6 +614,11 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
   na.iterations = (double*)iterations; na.rec = MO_NLS_ITER_RECORD(prm->max_line_search_iterations);
   na.termination = termination; na.num_iterations = num_iterations; na.status = status;
   na.counters = counters;
+  na.step = (double*)np->step; na.step_stride = np->step_stride; na.step_alpha = (double*)np->step_alpha;
+  na.user_exit = np->user_exit;
+  const bool retract_cb = prm->retraction == MO_RETRACT_CALLBACK;
+  if (retract_cb) MO_HIP_CHECK(hipMemsetAsync(np->step_alpha, 0, sizeof(double) * (size_t)batch, s));
+  if (np->user_exit) MO_HIP_CHECK(hipMemsetAsync(np->user_exit, 0, sizeof(int32_t) * (size_t)batch, s));
   MO_HIP_CHECK(mo::launch_nls_init(na, s));
   if (prm->max_iterations == 0) {  // nonlinear.cc:97, 157: no iteration at all
     MO_HIP_CHECK(hipMemsetAsync(termination, 0, sizeof(int32_t) * (size_t)batch, s));
@@ -676,6 +685,7 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
     MO_HIP_CHECK(mo::launch_cost_derivative(da, d.dtype, s));
     MO_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));
     MO_HIP_CHECK(mo::launch_nls_begin_search(na, s));
+    if (retract_cb && eval(user, MO_NLS_EVAL_RETRACT, stream) != 0) return fail(MO_ERR_CALLBACK, "eval(RETRACT) failed at iteration %d", iter);
     // SelectStepSize (nonlinear.cc:346-412)
     for (int ls = 0; ls <= prm->max_line_search_iterations; ++ls) {
       MO_HIP_CHECK(hipMemcpyAsync(host_counters, counters, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -687,8 +697,13 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
       MO_HIP_CHECK(mo::launch_nonlinear_errors(ea, d.dtype, s));
       MO_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int), s));
       MO_HIP_CHECK(mo::launch_nls_search_step(na, s));
+      if (retract_cb && eval(user, MO_NLS_EVAL_RETRACT, stream) != 0) return fail(MO_ERR_CALLBACK, "eval(RETRACT) failed at iteration %d", iter);
     }
     MO_HIP_CHECK(mo::launch_nls_update(na, s));
+    if (np->user_exit) {  // SetUserExitCallback, nonlinear.cc:142-149
+      if (eval(user, MO_NLS_EVAL_ITERATION_DONE, stream) != 0) return fail(MO_ERR_CALLBACK, "eval(ITERATION_DONE) failed at iteration %d", iter);
+      MO_HIP_CHECK(mo::launch_nls_user_exit(na, s));
+    }
     MO_HIP_CHECK(hipMemcpyAsync(host_counters, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MO_HIP_CHECK(hipStreamSynchronize(s));
     if (host_counters[1] == 0) break;  // every problem has terminated
@@ -708,6 +723,7 @@ int mo_residual_eval(mo_plan* plan, int32_t family, int32_t rows, const void* pa
   const int want = mo::residual_family_rows(family, d.n, rows);
   if (want < 0 || want != rows) return fail(MO_ERR_DIMENSION, "residual family %d with n = %d has %d rows, not %d", family, d.n, want, rows);
   if (family == MO_RESIDUAL_PRODUCT_PAIRS && !params) return fail(MO_ERR_INVALID_ARGUMENT, "PRODUCT_PAIRS needs params");
+  if (family == MO_RESIDUAL_ACTUATOR_CHAIN && !params) return fail(MO_ERR_INVALID_ARGUMENT, "ACTUATOR_CHAIN needs its parameter block");
   if (J) {
     if (J_layout != MO_ROW_MAJOR && J_layout != MO_COL_MAJOR) return fail(MO_ERR_INVALID_ARGUMENT, "bad J_layout");
     const int min_ld = J_layout == MO_ROW_MAJOR ? d.n : rows;

@@ -120,6 +120,8 @@ struct NlsArgs {
   double* iterations; int rec;                      // [batch][max_iterations][rec] or NULL
   int* termination; int* num_iterations; int* status;
   int* counters;                                    // [0] problems still in the line search, [1] problems still active
+  double* step; long long step_stride; double* step_alpha;  // MO_RETRACT_CALLBACK: dx and alpha handed to the caller's retraction
+  const int* user_exit;                             // SetUserExitCallback flags (NULL: none)
 };
 // device residual families (nls_kernels.hip); rows = -1 if (family, n, rows_hint) is not a valid combination
 int residual_family_rows(int family, int n, int rows_hint);
@@ -130,5 +132,6 @@ hipError_t launch_nls_init(const NlsArgs& a, hipStream_t stream);
 hipError_t launch_nls_begin_search(const NlsArgs& a, hipStream_t stream);
 hipError_t launch_nls_search_step(const NlsArgs& a, hipStream_t stream);
 hipError_t launch_nls_update(const NlsArgs& a, hipStream_t stream);
+hipError_t launch_nls_user_exit(const NlsArgs& a, hipStream_t stream);
 
 }  // namespace mo

@@ -138,6 +138,29 @@ __global__ __launch_bounds__(256) void nls_init_kernel(const NlsArgs a) {
   if (a.status) a.status[p] = MO_STATUS_OK;
 }
 
+// RetractCandidateVars (nonlinear.cc:160-168) for the built-in retractions; MO_RETRACT_CALLBACK hands (dx, alpha) to the caller instead.
+__device__ inline double mod_pi(double v) {  // math::ModPi: wrap into [-pi, pi)
+  const double two_pi = 6.283185307179586476925286766559, pi = 3.141592653589793238462643383279;
+  return v - two_pi * floor((v + pi) / two_pi);
+}
+__device__ inline void retract_candidate(const NlsArgs& a, long long p, double alpha, bool first, int lane) {
+  const double* x = a.vars + p * a.vars_stride; const double* dx = a.qp_vars + p * a.qp_vars_stride;
+  double* c = a.cand + p * a.cand_stride;
+  if (a.prm.retraction == MO_RETRACT_CALLBACK) {
+    if (first) {
+      double* st = a.step + p * a.step_stride;
+      for (int i = lane; i < a.n; i += 64) st[i] = dx[i];
+    }
+    if (lane == 0) a.step_alpha[p] = alpha;
+    return;
+  }
+  const bool wrap = a.prm.retraction == MO_RETRACT_WRAP_PI;
+  for (int i = lane; i < a.n; i += 64) {
+    const double v = x[i] + dx[i] * alpha;
+    c[i] = wrap ? mod_pi(v) : v;
+  }
+}
+
 // After the QP: penalty (nonlinear.cc:108-115, 485-500), directional derivative, first trial point alpha = 1 (:363, :160-168)
 __global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) {
   const int lane = threadIdx.x & 63;
@@ -184,9 +207,7 @@ __global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) 
     }
   }
   if (qp_status != MO_STATUS_OK) return;
-  const double* x = a.vars + p * a.vars_stride; const double* dx = a.qp_vars + p * a.qp_vars_stride;
-  double* c = a.cand + p * a.cand_stride;
-  for (int i = lane; i < a.n; i += 64) c[i] = x[i] + dx[i] * 1.0;
+  retract_candidate(a, p, 1.0, true, lane);                                                        // alpha = 1, :363
 }
 
 // One evaluation of the line search (nonlinear.cc:378-407) and, if it goes on, the next alpha (:364-376, 414-438)
@@ -242,9 +263,7 @@ __global__ __launch_bounds__(256) void nls_search_step_kernel(const NlsArgs a) {
     else { sd[NLS_SD_ALPHA] = next_alpha; atomicAdd(a.counters, 1); }
   }
   if (result >= 0) return;
-  const double* x = a.vars + p * a.vars_stride; const double* dx = a.qp_vars + p * a.qp_vars_stride;
-  double* c = a.cand + p * a.cand_stride;
-  for (int i = lane; i < a.n; i += 64) c[i] = x[i] + dx[i] * next_alpha;                          // RetractCandidateVars, :160-168
+  retract_candidate(a, p, next_alpha, false, lane);                                               // RetractCandidateVars, :160-168
 }
 
 // UpdateLambdaAndCheckExitConditions (nonlinear.cc:296-339) + the bookkeeping of the outer loop (:121-157)
@@ -289,6 +308,18 @@ __global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
     const int t = si[NLS_SI_TERM];
     if (a.termination) a.termination[p] = t >= 0 ? t : MO_NLS_MAX_ITERATIONS;                     // :157
     if (a.num_iterations) a.num_iterations[p] = si[NLS_SI_NITER];
+  }
+}
+
+// SetUserExitCallback (nonlinear.cc:142-149): a problem that is still active and whose flag the callback set ends with USER_CALLBACK
+__global__ __launch_bounds__(256) void nls_user_exit_kernel(const NlsArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.batch) return;
+  int* si = a.si + p * NLS_SI;
+  if (si[NLS_SI_TERM] < 0 && a.user_exit[p] != 0) {
+    si[NLS_SI_TERM] = MO_NLS_USER_CALLBACK;
+    if (a.termination) a.termination[p] = MO_NLS_USER_CALLBACK;
+    atomicSub(a.counters + 1, 1);
   }
 }
 
@@ -337,6 +368,10 @@ hipError_t launch_nls_search_step(const NlsArgs& a, hipStream_t stream) {
 }
 hipError_t launch_nls_update(const NlsArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(nls_update_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_nls_user_exit(const NlsArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(nls_user_exit_kernel, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -404,6 +439,120 @@ __global__ __launch_bounds__(256) void residual_family_kernel(int family, int n,
   r[p * r_stride + q] = val;
 }
 
+
+// MO_RESIDUAL_ACTUATOR_CHAIN: the reference's kinematic chains (test/transform_chains.cc) as a device residual family.  One thread
+// per problem walks the parameter block (wave-uniform scalar loads): per chain the link poses (ActuatorLink::Compute, :125-158), the
+// chain products and their derivatives (ComputeChain, :23-82) and the chain rule onto the active parameters (ActuatorChain::Update,
+// :202-243); then every residual row  const + sum lin_i x_i + sum_c w_c . t_c  with its Jacobian.
+constexpr int kChainMaxLinks = 8;
+
+template <typename T> __device__ inline void mat3_mul(const T (&A)[9], const T (&B)[9], T (&C)[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void actuator_chain_kernel(int n, int rows, long long batch, const T* prm, const T* x, long long x_stride, T* r,
+                                                            long long r_stride, T* J, long long J_stride, int J_ld, int row_major) {
+  const long long p = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (p >= batch) return;
+  const T* xp = x + p * x_stride;
+  T* rp = r + p * r_stride;
+  T* Jp = J ? J + p * J_stride : nullptr;
+  if (Jp)
+    for (int q = 0; q < rows; ++q)
+      for (int c = 0; c < n; ++c) put(Jp, q, c, rows, J_ld, row_major != 0, (T)0);
+  const int C = (int)prm[0];
+  // the row table starts behind the chains
+  int row_table = 1;
+  for (int c = 0; c < C; ++c) row_table += 1 + 12 * (int)prm[row_table];
+  {  // constant and linear parts
+    int pos = row_table;
+    for (int q = 0; q < rows; ++q) {
+      T val = prm[pos++];
+      const int nl = (int)prm[pos++];
+      for (int l = 0; l < nl; ++l) {
+        const int ix = (int)prm[pos]; const T cf = prm[pos + 1]; pos += 2;
+        val += cf * xp[ix];
+        if (Jp) { const size_t o = row_major ? (size_t)q * J_ld + ix : (size_t)ix * J_ld + q; Jp[o] += cf; }
+      }
+      const int nt = (int)prm[pos++];
+      pos += 4 * nt;
+      rp[q] = val;
+    }
+  }
+  int cpos = 1;
+  for (int c = 0; c < C; ++c) {
+    const int Ln = (int)prm[cpos];
+    const T* lk = prm + cpos + 1;
+    cpos += 1 + 12 * Ln;
+    T R[kChainMaxLinks][9], t[kChainMaxLinks][3], D[kChainMaxLinks][9], tend[kChainMaxLinks + 1][3];
+    for (int i = 0; i < Ln && i < kChainMaxLinks; ++i) {  // ActuatorLink::Compute: substitute the active parameters, R = Rx Ry Rz
+      T v[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) { const int ix = (int)lk[12 * i + 6 + d]; v[d] = ix >= 0 ? xp[ix] : lk[12 * i + d]; }
+      const T cx = cos(v[0]), sx = sin(v[0]), cy = cos(v[1]), sy = sin(v[1]), cz = cos(v[2]), sz = sin(v[2]);
+      const T Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx}, Ry[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy}, Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+      T Ryz[9];
+      mat3_mul(Ry, Rz, Ryz);
+      mat3_mul(Rx, Ryz, R[i]);
+      // right-tangent derivative of R wrt (x, y, z): (Ry Rz)^T e_x | Rz^T e_y | e_z   (rotation_D_angles)
+      D[i][0] = Ryz[0]; D[i][3] = Ryz[1]; D[i][6] = Ryz[2];
+      D[i][1] = Rz[3];  D[i][4] = Rz[4];  D[i][7] = Rz[5];
+      D[i][2] = 0;      D[i][5] = 0;      D[i][8] = 1;
+      t[i][0] = v[3]; t[i][1] = v[4]; t[i][2] = v[5];
+    }
+    tend[Ln][0] = tend[Ln][1] = tend[Ln][2] = 0;           // i_t_end, transform_chains.cc:47-52
+    for (int i = Ln - 1; i >= 0; --i)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) tend[i][a] = R[i][3 * a] * tend[i + 1][0] + R[i][3 * a + 1] * tend[i + 1][1] + R[i][3 * a + 2] * tend[i + 1][2] + t[i][a];
+    // rows that look at this chain
+    T S[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};                  // start_R_i, :56-61
+    for (int i = 0; i < Ln; ++i) {
+      T Sn[9];
+      mat3_mul(S, R[i], Sn);
+      for (int d = 0; d < 6; ++d) {
+        const int ix = (int)lk[12 * i + 6 + d];
+        if (ix < 0) continue;
+        T dt[3];                                           // d(effector translation) / d(parameter)
+        if (d >= 3) {                                      // translation_D_translation column, :56-61, 231-241
+          dt[0] = S[d - 3]; dt[1] = S[3 + d - 3]; dt[2] = S[6 + d - 3];
+        } else if (i < Ln - 1) {                           // start_R_[i+1] [-[i+1]_t_N]_x rot_D_angles[:, d], :66-73, 221-222
+          const T v0 = D[i][d], v1 = D[i][3 + d], v2 = D[i][6 + d];
+          const T* te = tend[i + 1];
+          const T w0 = v1 * te[2] - v2 * te[1], w1 = v2 * te[0] - v0 * te[2], w2 = v0 * te[1] - v1 * te[0];   // v x t = [-t]_x v
+          dt[0] = Sn[0] * w0 + Sn[1] * w1 + Sn[2] * w2; dt[1] = Sn[3] * w0 + Sn[4] * w1 + Sn[5] * w2; dt[2] = Sn[6] * w0 + Sn[7] * w1 + Sn[8] * w2;
+        } else {
+          dt[0] = dt[1] = dt[2] = 0;                       // the last link's rotation does not move the effector, :73
+        }
+        if (!Jp) continue;
+        int pos = row_table;
+        for (int q = 0; q < rows; ++q) {
+          pos += 1; const int nl = (int)prm[pos++]; pos += 2 * nl;
+          const int nt = (int)prm[pos++];
+          for (int e = 0; e < nt; ++e, pos += 4) {
+            if ((int)prm[pos] != c) continue;
+            const T g = prm[pos + 1] * dt[0] + prm[pos + 2] * dt[1] + prm[pos + 3] * dt[2];
+            const size_t o = row_major ? (size_t)q * J_ld + ix : (size_t)ix * J_ld + q;
+            Jp[o] += g;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) S[e] = Sn[e];
+    }
+    int pos = row_table;                                   // values: w . t_effector with t_effector = 0_t_N
+    for (int q = 0; q < rows; ++q) {
+      pos += 1; const int nl = (int)prm[pos++]; pos += 2 * nl;
+      const int nt = (int)prm[pos++];
+      for (int e = 0; e < nt; ++e, pos += 4)
+        if ((int)prm[pos] == c) rp[q] += prm[pos + 1] * tend[0][0] + prm[pos + 2] * tend[0][1] + prm[pos + 3] * tend[0][2];
+    }
+  }
+}
+
 }  // namespace
 
 int residual_family_rows(int family, int n, int rows_hint) {
@@ -412,6 +561,7 @@ int residual_family_rows(int family, int n, int rows_hint) {
     case MO_RESIDUAL_HIMMELBLAU: return n == 2 ? 2 : -1;
     case MO_RESIDUAL_SPHERE: return n;
     case MO_RESIDUAL_PRODUCT_PAIRS: return (rows_hint >= 1 && 2 * rows_hint <= n) ? rows_hint : -1;
+    case MO_RESIDUAL_ACTUATOR_CHAIN: return rows_hint >= 1 ? rows_hint : -1;   // the rows are described by the parameter block
     default: return -1;
   }
 }
@@ -420,6 +570,16 @@ hipError_t launch_residual_family(int family, int n, int rows, long long batch, 
                                   long long x_stride, void* r, long long r_stride, void* J, long long J_stride, int J_ld,
                                   int row_major, hipStream_t stream) {
   if (batch <= 0 || rows <= 0) return hipSuccess;
+  if (family == MO_RESIDUAL_ACTUATOR_CHAIN) {
+    const dim3 cg((unsigned)((batch + 63) / 64)), cb(64);
+    if (dtype == MO_F64)
+      hipLaunchKernelGGL(actuator_chain_kernel<double>, cg, cb, 0, stream, n, rows, batch, (const double*)prm, (const double*)x, x_stride,
+                         (double*)r, r_stride, (double*)J, J_stride, J_ld, row_major);
+    else
+      hipLaunchKernelGGL(actuator_chain_kernel<float>, cg, cb, 0, stream, n, rows, batch, (const float*)prm, (const float*)x, x_stride,
+                         (float*)r, r_stride, (float*)J, J_stride, J_ld, row_major);
+    return hipGetLastError();
+  }
   const long long total = batch * rows;
   const dim3 gd((unsigned)((total + 255) / 256)), bd(256);
   if (dtype == MO_F64)

@@ -61,17 +61,45 @@ class Params:
     max_lambda: float = 1.0
     min_lambda: float = 0.0
 
-    def as_struct(self) -> L.NlsParams:
+    def as_struct(self, retraction: int = L.MO_RETRACT_EUCLIDEAN) -> L.NlsParams:
         p = L.NlsParams()
         L.lib().mo_default_nls_params(C.byref(p))
         for name, _ in L.NlsParams._fields_:
-            setattr(p, name, getattr(self, name))
+            if hasattr(self, name):
+                setattr(p, name, getattr(self, name))
+        p.retraction = int(retraction)   # the Retraction is a constructor argument of the solver (nonlinear.hpp:127), not a Param
         return p
 
 
 ResidualFn = Callable[[torch.Tensor, bool], Tuple[torch.Tensor, Optional[torch.Tensor]]]
 
-ROSENBROCK, HIMMELBLAU, SPHERE, PRODUCT_PAIRS = range(4)  # mo_residual_family
+ROSENBROCK, HIMMELBLAU, SPHERE, PRODUCT_PAIRS, ACTUATOR_CHAIN = range(5)  # mo_residual_family
+WRAP_PI = "wrap_pi"  # built-in retraction: x + alpha dx wrapped into [-pi, pi) (the reference's robot tests, nonlinear_test.cc:874-880)
+
+
+def actuator_chain_params(chains, rows, dtype=torch.float64, device="cuda:0") -> torch.Tensor:
+    """Parameter block of the ACTUATOR_CHAIN device family (layout: include/mini_opt_hip.h).
+    chains: list of chains, each a list of links dict(rotation_xyz=(3), translation=(3), mask=(6 flags), params=(x index per active flag));
+    rows:   list of dict(const=float, lin={x index: coefficient}, terms=[(chain, wx, wy, wz), ...])."""
+    out = [float(len(chains))]
+    for links in chains:
+        if len(links) > 8:
+            raise L.MiniOptError(-3, "ACTUATOR_CHAIN: at most 8 links per chain")
+        out.append(float(len(links)))
+        for l in links:
+            out.extend(float(v) for v in l["rotation_xyz"])
+            out.extend(float(v) for v in l["translation"])
+            idx = iter(l["params"])
+            out.extend(float(next(idx)) if flag else -1.0 for flag in l["mask"])
+    for row in rows:
+        out.append(float(row["const"]))
+        out.append(float(len(row["lin"])))
+        for i, cf in row["lin"].items():
+            out.extend((float(i), float(cf)))
+        out.append(float(len(row["terms"])))
+        for c, wx, wy, wz in row["terms"]:
+            out.extend((float(c), float(wx), float(wy), float(wz)))
+    return torch.tensor(out, dtype=dtype, device=device)
 
 
 @dataclass
@@ -145,7 +173,9 @@ class _Plan:
 class ConstrainedNonlinearLeastSquares:
     """Batched mirror of mini_opt::ConstrainedNonlinearLeastSquares (nonlinear.hpp:127-230)."""
 
-    def __init__(self, problem: Problem, batch: int, device=None, dtype=torch.float64):
+    def __init__(self, problem: Problem, batch: int, device=None, dtype=torch.float64, retraction=None):
+        """retraction: None = x + alpha dx; WRAP_PI = the built-in angle wrap; or a callable (x [B, n], dx [B, n], alpha [B]) ->
+        candidate [B, n] on torch tensors -- the reference's custom Retraction (nonlinear.hpp:127, nonlinear.cc:160-168)."""
         if problem is None:
             raise L.MiniOptError(-1, "Must have a valid problem")          # F_ASSERT nonlinear.cc:78
         if dtype != torch.float64:
@@ -168,10 +198,34 @@ class ConstrainedNonlinearLeastSquares:
             self.cons_b = torch.tensor([[c[2] for c in problem.inequality_constraints]], dtype=dtype, device=dev)
         else:
             self.cons_var = self.cons_a = self.cons_b = None
+        self.retraction_ = retraction
+        self._retract_code = (L.MO_RETRACT_EUCLIDEAN if retraction is None else L.MO_RETRACT_WRAP_PI if retraction == WRAP_PI
+                              else L.MO_RETRACT_CALLBACK)
+        self.step_, self.step_alpha_ = (z(B, n), z(B)) if self._retract_code == L.MO_RETRACT_CALLBACK else (None, None)
+        self.user_exit_callback_ = None
+        self.user_exit_ = None
+        self._outputs_view = None
+
+    def SetUserExitCallback(self, callback) -> None:
+        """nonlinear.hpp:157: callback(iteration index, NLSSolverOutputs view of the records so far) -> bool, or a bool tensor [B]
+        (False = stop that problem).  A stopped problem ends with USER_CALLBACK unless the iteration terminated it anyway."""
+        self.user_exit_callback_ = callback
+        self.user_exit_ = torch.zeros(self.batch, dtype=torch.int32, device=self.variables_.device) if callback is not None else None
 
     # ---- callbacks: enqueue the user's residual evaluation on the stream the library works on
     def _eval(self, user, what, stream):
         try:
+            if what == L.MO_NLS_EVAL_RETRACT:                  # the caller's Retraction, nonlinear.cc:160-168
+                self.candidate_vars_.copy_(self.retraction_(self.variables_, self.step_, self.step_alpha_))
+                return 0
+            if what == L.MO_NLS_EVAL_ITERATION_DONE:           # SetUserExitCallback, nonlinear.cc:142-149
+                self._iter_done += 1
+                proceed = self.user_exit_callback_(self._iter_done - 1, self._outputs_view)
+                if isinstance(proceed, torch.Tensor):
+                    self.user_exit_.copy_((~proceed.to(torch.bool)).to(torch.int32))
+                else:
+                    self.user_exit_.fill_(0 if proceed else 1)
+                return 0
             lin = what == L.MO_NLS_EVAL_LINEARIZE
             x = self.variables_ if lin else self.candidate_vars_
             r_buf = self.r if lin else self.r_cand
@@ -210,6 +264,10 @@ class ConstrainedNonlinearLeastSquares:
             p.r_eq_cand, p.r_eq_cand_stride = _ptr(self.r_eq_cand), k
         if m:
             p.cons_var, p.cons_a, p.cons_b, p.cons_stride = _ptr(self.cons_var), _ptr(self.cons_a), _ptr(self.cons_b), 0
+        if self.step_ is not None:
+            p.step, p.step_stride, p.step_alpha = _ptr(self.step_), n, _ptr(self.step_alpha_)
+        if self.user_exit_ is not None:
+            p.user_exit = _ptr(self.user_exit_)
         return p
 
     def Solve(self, params: Params, variables: torch.Tensor) -> NLSSolverOutputs:
@@ -224,9 +282,11 @@ class ConstrainedNonlinearLeastSquares:
         nit = torch.zeros(B, dtype=torch.int32, device=dev)
         status = torch.zeros(B, dtype=torch.int32, device=dev)
         its = torch.full((B, max(params.max_iterations, 1), rec), float("nan"), dtype=torch.float64, device=dev)
-        sp = params.as_struct()
+        sp = params.as_struct(self._retract_code)
         prob = self._problem_struct()
         self._callback_error = None
+        self._iter_done = 0
+        self._outputs_view = NLSSolverOutputs(term, nit, its, status)
         cb = L.NLS_EVAL_FN(self._eval)
         rc = L.lib().mo_nls_solve(self._plan.h, C.byref(prob), B, C.byref(sp), cb, None, _ptr(term), _ptr(nit), _ptr(its),
                                   _ptr(status), _stream())

@@ -430,3 +430,139 @@ def test_nls_isolates_a_failing_problem_and_handles_degenerate_calls():
     calls["n"] = 0
     out0 = nls.Solve(NLS.Params(max_iterations=0), T(np.array(P.ROSENBROCK_GUESSES, dtype=float)))
     assert calls["n"] == 0 and torch.all(out0.termination_state == NLS.MAX_ITERATIONS) and torch.all(out0.num_iterations == 0)
+
+
+# ---- kinematic-chain robots (row f2): nonlinear_test.cc:828-1136 on the device -------------------------------------------------------
+def _chain_family(spec, rows):
+    return NLS.DeviceFamily(NLS.ACTUATOR_CHAIN, len(rows), NLS.actuator_chain_params(spec["chains"], rows))
+
+
+def _effector_xy(spec, x):
+    return np.stack([P.chain_effector_np(spec, 0, v)[:2] for v in x])
+
+
+def test_actuator_chain_family_matches_the_chain_restatement():
+    """MO_RESIDUAL_ACTUATOR_CHAIN against oracle/chain_oracle.py (ComputeChain / ActuatorChain::Update restated, pinned by numerical
+    derivatives): the rows of both robot problems, and a general chain with base rotations and every kind of active parameter."""
+    rng = np.random.default_rng(5)
+    general = dict(n=7, chains=[[P.chain_link((1.0, 0.5, 2.0), (1, 0, 1, 0, 1, 0), (0, 1, 2), rotation_xyz=(-0.5, 0.5, 0.3)),
+                                 P.chain_link((0.5, 0.75, -0.5), (0, 1, 0, 0, 0, 0), (3,), rotation_xyz=(0.8, 0.5, 1.2)),
+                                 P.chain_link((1.2, -0.5, 0.1), (0, 0, 0, 1, 0, 1), (4, 5), rotation_xyz=(1.5, -0.2, 0.0)),
+                                 P.chain_link((0.1, -0.1, 0.2), (1, 1, 1, 0, 0, 0), (6, 0, 2), rotation_xyz=(0.2, -0.1, 0.3))]])
+    general_rows = [P.chain_row(0.3, lin={1: -0.7, 6: 0.2}, terms=[(0, 1.0, -2.0, 0.5)]), P.chain_row(-1.0, terms=[(0, 0.0, 0.0, 1.0)]),
+                    P.chain_row(0.0, lin={3: 1.5})]
+    for spec, rows in ((P.TWO_ANGLE, P.TWO_ANGLE["cost_rows"] + P.TWO_ANGLE["eq_rows"]), (P.DUAL, P.DUAL["cost_rows"] + P.DUAL["eq_rows"]),
+                       (general, general_rows)):
+        B, n = 17, spec["n"]
+        x = rng.uniform(-1.2, 1.2, (B, n))
+        fam = _chain_family(spec, rows)
+        r, J = fam(T(x), True)
+        fn = P.chain_rows_np(spec, rows)
+        for p in range(B):
+            r0, J0 = fn(x[p], True)
+            np.testing.assert_allclose(r[p].cpu().numpy(), r0, rtol=0, atol=1e-14)
+            np.testing.assert_allclose(J[p].cpu().numpy(), J0, rtol=0, atol=1e-14)
+        r_only, none = fam(T(x), False)
+        assert none is None and torch.equal(r_only, r)
+
+
+def _run_two_angle(stage, retraction):
+    spec = P.TWO_ANGLE
+    guesses = np.array(P.two_angle_guesses(stage))
+    prm = dict(spec["params"])
+    cons = []
+    if stage == 2:
+        prm["max_qp_iterations"] = 10
+        cons = spec["inequalities_stage2"]
+    prob = NLS.Problem(2, _chain_family(spec, spec["cost_rows"]), cost_rows=1, equality=_chain_family(spec, spec["eq_rows"]), equality_rows=1,
+                       inequality_constraints=cons)
+    nls = NLS.ConstrainedNonlinearLeastSquares(prob, batch=len(guesses), retraction=retraction)
+    out = nls.Solve(NLS.Params(**prm), T(guesses))
+    return spec, guesses, prm, cons, nls, out
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_two_angle_actuator_chain_on_device(stage):
+    """TestTwoAngleActuatorChain (nonlinear_test.cc:828-964), every initial guess one problem of the batch, residuals from the device
+    chain family, the reference's ModPi retraction built in (WRAP_PI): the reference's assertions (effector within 5e-5 / 1e-3 of the
+    target, < 100 line-search steps) and the oracle's termination state and iteration count problem by problem."""
+    spec, guesses, prm, cons, nls, out = _run_two_angle(stage, NLS.WRAP_PI)
+    x = nls.variables().cpu().numpy()
+    assert torch.all(out.status == 0)
+    np.testing.assert_allclose(_effector_xy(spec, x), np.tile(spec["target_xy"], (len(x), 1)), atol=5e-5 if stage == 1 else 1e-3)
+    assert int(out.NumLineSearchSteps().max()) < 100
+    term, nit = out.termination_state.cpu().numpy(), out.num_iterations.cpu().numpy()
+    cost, eq = P.chain_rows_np(spec, spec["cost_rows"]), P.chain_rows_np(spec, spec["eq_rows"])
+    same = 0
+    for p, g in enumerate(guesses):
+        o = N.ConstrainedNonlinearLeastSquares(N.Problem(2, cost, equality=eq, inequality_constraints=cons), retraction=P.mod_pi_retraction_np)
+        t, logs = o.solve(N.Params(**prm), g)
+        if t == term[p] and len(logs) == nit[p]:
+            same += 1
+            np.testing.assert_allclose(x[p], o.variables, atol=1e-6)
+    assert same >= 0.97 * len(guesses), (same, len(guesses))   # knife-edge line-search decisions may flip with rounding in a few starts
+
+
+def test_two_angle_with_a_callback_retraction_matches_the_builtin():
+    """The caller's own Retraction (nonlinear.hpp:127) through MO_RETRACT_CALLBACK: the same ModPi wrap written with torch ops gives the
+    results of the built-in one bit for bit."""
+    def wrap(x, dx, alpha):
+        v = x + dx * alpha[:, None]
+        return v - 2 * np.pi * torch.floor((v + np.pi) / (2 * np.pi))
+    _, _, _, _, nls_a, out_a = _run_two_angle(1, NLS.WRAP_PI)
+    _, _, _, _, nls_b, out_b = _run_two_angle(1, wrap)
+    assert torch.equal(out_a.termination_state, out_b.termination_state) and torch.equal(out_a.num_iterations, out_b.num_iterations)
+    np.testing.assert_allclose(nls_a.variables().cpu().numpy(), nls_b.variables().cpu().numpy(), rtol=0, atol=1e-13)
+
+
+def test_dual_actuator_balancing_on_device():
+    """TestDualActuatorBalancing (nonlinear_test.cc:966-1136) on the device: SATISFIED_ABSOLUTE_TOL from all three guesses, every
+    residual's quadratic error below 1e-8, fewer than 36 line-search steps; same termination and iteration count as the oracle."""
+    spec = P.DUAL
+    guesses = np.array(spec["guesses"])
+    prob = NLS.Problem(5, _chain_family(spec, spec["cost_rows"]), cost_rows=2, equality=_chain_family(spec, spec["eq_rows"]), equality_rows=2,
+                       inequality_constraints=spec["inequalities"])
+    nls = NLS.ConstrainedNonlinearLeastSquares(prob, batch=len(guesses), retraction=NLS.WRAP_PI)
+    out = nls.Solve(NLS.Params(**spec["params"]), T(guesses))
+    assert torch.all(out.termination_state == NLS.SATISFIED_ABSOLUTE_TOL) and torch.all(out.status == 0)
+    x = nls.variables().cpu().numpy()
+    cost, eq = P.chain_rows_np(spec, spec["cost_rows"]), P.chain_rows_np(spec, spec["eq_rows"])
+    for p, g in enumerate(guesses):
+        for fn in (cost, eq):
+            r, _ = fn(x[p], False)
+            assert np.all(0.5 * r * r <= 1e-8)
+        o = N.ConstrainedNonlinearLeastSquares(N.Problem(5, cost, equality=eq, inequality_constraints=spec["inequalities"]),
+                                               retraction=P.mod_pi_retraction_np)
+        t, logs = o.solve(N.Params(**spec["params"]), g)
+        assert t == NLS.SATISFIED_ABSOLUTE_TOL and len(logs) == int(out.num_iterations[p])
+        # 5 angles, 4 conditions: the optimum is a one-parameter family, only the damped steps pick a point on it -- rounding moves it
+        np.testing.assert_allclose(x[p], o.variables, atol=1e-4)
+    assert int(out.NumLineSearchSteps().max()) < 36
+
+
+def test_user_exit_callback_on_device():
+    """SetUserExitCallback (nonlinear.hpp:157, nonlinear.cc:142-149): stopping the odd problems after their first iteration ends them
+    with USER_CALLBACK after exactly one iteration (Gauss-Newton needs two on Rosenbrock); the even ones run on to their optimum; a
+    callback that always proceeds changes nothing."""
+    guesses = np.array(P.ROSENBROCK_GUESSES, dtype=float)
+    B = len(guesses)
+    nls = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, P.rosenbrock_torch, cost_rows=2), batch=B)
+    odd = torch.arange(B, device="cuda:0") % 2 == 1
+    seen = []
+
+    def cb(iteration, outputs):
+        seen.append(iteration)
+        assert outputs.iterations.shape[0] == B
+        return ~odd
+    nls.SetUserExitCallback(cb)
+    out = nls.Solve(NLS.Params(max_iterations=10, max_qp_iterations=1), T(guesses))
+    term, nit = out.termination_state.cpu().numpy(), out.num_iterations.cpu().numpy()
+    assert seen[:2] == [0, 1]
+    assert np.all(term[1::2] == NLS.USER_CALLBACK) and np.all(nit[1::2] == 1)
+    assert np.all(term[0::2] == NLS.SATISFIED_ABSOLUTE_TOL)
+    np.testing.assert_allclose(nls.variables().cpu().numpy()[0::2], 1.0, atol=1e-6)
+    nls.SetUserExitCallback(lambda it, o: True)
+    out2 = nls.Solve(NLS.Params(max_iterations=10, max_qp_iterations=1), T(guesses))
+    nls.SetUserExitCallback(None)
+    out3 = nls.Solve(NLS.Params(max_iterations=10, max_qp_iterations=1), T(guesses))
+    assert torch.equal(out2.termination_state, out3.termination_state) and torch.equal(out2.num_iterations, out3.num_iterations)
