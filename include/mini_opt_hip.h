@@ -292,6 +292,9 @@ typedef struct {
                                         outer iteration eval(user, MO_NLS_EVAL_ITERATION_DONE, stream) is called (the iteration's record is in
                                         `iterations`, the state in `vars`); a problem whose flag it sets non-zero ends with
                                         MO_NLS_USER_CALLBACK unless that iteration terminated it anyway.  Zeroed by mo_nls_solve on entry. */
+  void* qp_iterations;               /* NULL, or [max_iterations][batch][max_qp_iterations][MO_ITER_RECORD]: the QPInteriorPointIteration records
+                                        of every outer iteration's QP (NLSIteration::qp_outputs, structs.hpp:288); the caller pre-fills NaN */
+  void* qp_lagrange;                 /* NULL, or [max_iterations][batch][2]: QPLagrangeMultipliers {min, l_infinity} of each QP (k > 0) */
 } mo_nls_problem;
 
 typedef int (*mo_nls_eval_fn)(void* user, int32_t what, void* stream);  /* non-zero return aborts mo_nls_solve with MO_ERR_CALLBACK */

@@ -72,7 +72,8 @@ class NlsProblem(C.Structure):
                 ("r_eq", C.c_void_p), ("r_eq_stride", C.c_int64),
                 ("r_cand", C.c_void_p), ("r_cand_stride", C.c_int64), ("r_eq_cand", C.c_void_p), ("r_eq_cand_stride", C.c_int64),
                 ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64),
-                ("step", C.c_void_p), ("step_stride", C.c_int64), ("step_alpha", C.c_void_p), ("user_exit", C.c_void_p)]
+                ("step", C.c_void_p), ("step_stride", C.c_int64), ("step_alpha", C.c_void_p), ("user_exit", C.c_void_p),
+                ("qp_iterations", C.c_void_p), ("qp_lagrange", C.c_void_p)]
 
 
 NLS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)

@@ -20,7 +20,10 @@
 
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
+#include <array>
 #include <exception>
+#include <memory>
 #include <functional>
 #include <limits>
 #include <optional>
@@ -326,6 +329,36 @@ enum class NLSTerminationState { MAX_ITERATIONS = 0, SATISFIED_ABSOLUTE_TOL, SAT
                                  MAX_LAMBDA, QP_INDEFINITE, USER_CALLBACK, QP_FAILURE };                  // structs.hpp:233-248
 enum class LineSearchStrategy { ARMIJO_BACKTRACK = 0, POLYNOMIAL_APPROXIMATION = 1 };                    // structs.hpp:148-153
 
+enum class OptimizerState { NOMINAL = 0, ATTEMPTING_RESTORE_LM = 1 };                                    // structs.hpp:156-165
+enum class StepSizeSelectionResult { SUCCESS = 0, MAX_ITERATIONS, FIRST_ORDER_SATISFIED, POSITIVE_DERIVATIVE, FAILURE_NON_FINITE_COST,
+                                     FAILURE_INVALID_ALPHA };                                            // structs.hpp:215-228
+struct Errors {                                                                                          // structs.hpp:169-186
+  double f{0.}, equality{0.};
+  double Total(double penalty) const noexcept { return f + penalty * equality; }
+  double LInfinity() const noexcept { return std::max(f, equality); }
+};
+struct DirectionalDerivatives { double d_f{0.}, d_equality{0.}; double Total(double penalty) const noexcept { return d_f + penalty * d_equality; } };  // :189-203
+struct LineSearchStep { double alpha; Errors errors; };                                                  // structs.hpp:206-213
+// NLSIteration (structs.hpp:277-330).  qp_outputs is summarised: termination state and iteration count of the interior-point QP (or the
+// null-space solver's state for equality-only problems, nonlinear.cc:249-258) and the QP's per-problem status word.
+struct NLSIteration {
+  int iteration{0};
+  OptimizerState optimizer_state{OptimizerState::NOMINAL};
+  double lambda{0.};
+  Errors errors_initial{};
+  int qp_termination_state{0}, qp_num_iterations{0}, qp_status{0};
+  DirectionalDerivatives directional_derivatives{};
+  double penalty{0.};
+  StepSizeSelectionResult step_result{StepSizeSelectionResult::SUCCESS};
+  std::vector<LineSearchStep> line_search_steps;
+};
+struct NLSSolverOutputs {                                                                                // structs.hpp:332-347
+  NLSTerminationState termination_state{NLSTerminationState::MAX_ITERATIONS};
+  std::vector<NLSIteration> iterations;
+  int NumLineSearchSteps() const { int c = 0; for (const auto& it : iterations) c += (int)it.line_search_steps.size(); return c; }
+  int NumQPIterations() const { int c = 0; for (const auto& it : iterations) c += it.qp_num_iterations; return c; }
+};
+
 class BatchedConstrainedNonlinearLeastSquares {
  public:
   struct Params {                                                                                        // nonlinear.hpp:64-124
@@ -351,6 +384,14 @@ class BatchedConstrainedNonlinearLeastSquares {
   // x: [batch][n] evaluation points.  r: [batch][m_r], J: [batch][m_r][n] row-major (NULL when only errors are wanted),
   // r_eq: [batch][k], J_eq: [batch][k][n] row-major (both NULL when k == 0).
   using HostResiduals = std::function<void(const double* x, int64_t batch, double* r, double* J, double* r_eq, double* J_eq)>;
+  // The reference's Retraction (nonlinear.hpp:127; applied in RetractCandidateVars, nonlinear.cc:160-168): x enters as the current
+  // variables of one problem and leaves as the trial point for step dx and step length alpha.
+  using Retraction = std::function<void(std::vector<double>& x, const VectorBlock& dx, double alpha)>;
+  // SetUserExitCallback (nonlinear.hpp:157): called per problem after every outer iteration it took part in; false stops that problem
+  // (USER_CALLBACK) unless the iteration terminated it anyway (nonlinear.cc:142-149).
+  using UserExitCallback = std::function<bool(int64_t problem, const NLSIteration& iteration)>;
+  void SetRetraction(Retraction r) { retraction_ = std::move(r); }
+  void SetUserExitCallback(UserExitCallback cb) { user_exit_ = std::move(cb); }
 
   BatchedConstrainedNonlinearLeastSquares(int n, int m_r, int k, std::vector<LinearInequalityConstraint> inequality_constraints,
                                           HostResiduals residuals, int64_t batch, int device = 0)
@@ -386,6 +427,7 @@ class BatchedConstrainedNonlinearLeastSquares {
     sp.lambda_initial = p.lambda_initial; sp.lambda_failure_init = p.lambda_failure_init;
     sp.lambda_decrease_on_success = p.lambda_decrease_on_success; sp.lambda_decrease_on_restore = p.lambda_decrease_on_restore;
     sp.max_lambda = p.max_lambda; sp.min_lambda = p.min_lambda;
+    sp.retraction = retraction_ ? MO_RETRACT_CALLBACK : MO_RETRACT_EUCLIDEAN;
     mo_nls_problem np{};
     np.vars = vars_.get(); np.vars_stride = n_; np.candidate = cand_.get(); np.candidate_stride = n_;
     np.J = J_.get(); np.J_stride = (int64_t)m_r_ * n_; np.J_ld = n_; np.J_layout = MO_ROW_MAJOR; np.r = r_.get(); np.r_stride = m_r_;
@@ -395,19 +437,42 @@ class BatchedConstrainedNonlinearLeastSquares {
       np.r_eq_cand = req_cand_.get(); np.r_eq_cand_stride = k_;
     }
     if (m_ > 0) { np.cons_var = cv_.get(); np.cons_a = ca_.get(); np.cons_b = cb_.get(); np.cons_stride = 0; }
+    if (retraction_) { step_.Resize((size_t)batch_ * n_); step_alpha_.Resize((size_t)batch_); np.step = step_.get(); np.step_stride = n_; np.step_alpha = step_alpha_.get(); }
+    if (user_exit_) { exit_flags_.Resize((size_t)batch_); np.user_exit = exit_flags_.get(); }
     detail::DeviceBuffer<int32_t> term((size_t)batch_), nit((size_t)batch_);
+    rec_ = MO_NLS_ITER_RECORD(p.max_line_search_iterations);
+    max_iterations_ = p.max_iterations > 0 ? p.max_iterations : 1;
+    records_.Resize((size_t)batch_ * max_iterations_ * rec_);
+    {  // records of iterations a problem never ran stay NaN
+      std::vector<double> nanfill((size_t)batch_ * max_iterations_ * rec_, std::numeric_limits<double>::quiet_NaN());
+      records_.Upload(nanfill.data(), nanfill.size());
+    }
+    iterations_done_ = 0;
+    term_dev_ = term.get(); nit_dev_ = nit.get();
     callback_error_ = nullptr;
     const int rc = mo_nls_solve(plan_, &np, batch_, &sp, &BatchedConstrainedNonlinearLeastSquares::Eval, this, term.get(), nit.get(),
-                                nullptr, nullptr, nullptr);
+                                records_.get(), nullptr, nullptr);
     if (callback_error_) std::rethrow_exception(callback_error_);
     detail::check(rc);
     variables_.resize((size_t)batch_ * n_); vars_.Download(variables_.data(), variables_.size());
     num_iterations_.resize((size_t)batch_); nit.Download(num_iterations_.data(), num_iterations_.size());
     std::vector<int32_t> t((size_t)batch_); term.Download(t.data(), t.size());
+    std::vector<double> rec((size_t)batch_ * max_iterations_ * rec_); records_.Download(rec.data(), rec.size());
+    outputs_.assign((size_t)batch_, NLSSolverOutputs{});
     std::vector<NLSTerminationState> out;
-    for (int32_t v : t) out.push_back((NLSTerminationState)v);
+    for (int64_t b = 0; b < batch_; ++b) {
+      out.push_back((NLSTerminationState)t[(size_t)b]);
+      outputs_[(size_t)b].termination_state = out.back();
+      for (int it = 0; it < num_iterations_[(size_t)b] && it < max_iterations_; ++it) {
+        const double* r = rec.data() + ((size_t)b * max_iterations_ + it) * rec_;
+        if (std::isnan(r[1])) break;  // QP_INDEFINITE ends a problem without logging the iteration (nonlinear.cc:103-105)
+        outputs_[(size_t)b].iterations.push_back(Record(r, it));
+      }
+    }
     return out;
   }
+  // NLSSolverOutputs (structs.hpp:332-347) of every problem of the last Solve.
+  const std::vector<NLSSolverOutputs>& outputs() const { return outputs_; }
   const std::vector<double>& variables() const { return variables_; }          // [batch][n]
   const std::vector<int32_t>& num_iterations() const { return num_iterations_; }
 
@@ -415,6 +480,8 @@ class BatchedConstrainedNonlinearLeastSquares {
   static int Eval(void* user, int32_t what, void* stream) {
     auto* self = static_cast<BatchedConstrainedNonlinearLeastSquares*>(user);
     try {
+      if (what == MO_NLS_EVAL_RETRACT) { self->Retract((hipStream_t)stream); return 0; }
+      if (what == MO_NLS_EVAL_ITERATION_DONE) { self->IterationDone((hipStream_t)stream); return 0; }
       const bool lin = what == MO_NLS_EVAL_LINEARIZE;
       const size_t B = (size_t)self->batch_, n = (size_t)self->n_, k = (size_t)self->k_;
       (void)hipStreamSynchronize((hipStream_t)stream);  // the evaluation point is produced by device work on this stream
@@ -438,15 +505,229 @@ class BatchedConstrainedNonlinearLeastSquares {
       return 1;
     }
   }
+  NLSIteration Record(const double* r, int it) const {   // MO_NLS_ITER_RECORD layout, include/mini_opt_hip.h
+    NLSIteration o;
+    o.iteration = it; o.optimizer_state = (OptimizerState)(int)r[0]; o.lambda = r[1]; o.errors_initial = {r[2], r[3]};
+    o.directional_derivatives = {r[4], r[5]}; o.penalty = r[6];
+    o.step_result = std::isnan(r[7]) ? StepSizeSelectionResult::SUCCESS : (StepSizeSelectionResult)(int)r[7];
+    const int ns = std::isnan(r[8]) ? 0 : (int)r[8];
+    o.qp_termination_state = std::isnan(r[9]) ? 0 : (int)r[9]; o.qp_num_iterations = std::isnan(r[10]) ? 0 : (int)r[10];
+    o.qp_status = std::isnan(r[11]) ? 0 : (int)r[11];
+    for (int s = 0; s < ns; ++s) o.line_search_steps.push_back({r[MO_NLS_ITER_HEADER + 3 * s], {r[MO_NLS_ITER_HEADER + 3 * s + 1], r[MO_NLS_ITER_HEADER + 3 * s + 2]}});
+    return o;
+  }
+  void Retract(hipStream_t stream) {   // the caller's Retraction on the host, problem by problem (nonlinear.cc:160-168)
+    const size_t B = (size_t)batch_, n = (size_t)n_;
+    (void)hipStreamSynchronize(stream);
+    h_x_.resize(B * n); h_step_.resize(B * n); h_alpha_.resize(B);
+    vars_.Download(h_x_.data(), B * n); step_.Download(h_step_.data(), B * n); step_alpha_.Download(h_alpha_.data(), B);
+    std::vector<double> x(n);
+    for (size_t b = 0; b < B; ++b) {
+      x.assign(h_x_.begin() + b * n, h_x_.begin() + (b + 1) * n);
+      retraction_(x, VectorBlock{h_step_.data() + b * n, (int)n}, h_alpha_[b]);
+      std::copy(x.begin(), x.end(), h_x_.begin() + b * n);
+    }
+    cand_.Upload(h_x_.data(), B * n);
+  }
+  void IterationDone(hipStream_t stream) {   // SetUserExitCallback, nonlinear.cc:142-149
+    const size_t B = (size_t)batch_;
+    (void)hipStreamSynchronize(stream);
+    std::vector<int32_t> nit(B), flags(B, 0);
+    detail::hip_check(hipMemcpy(nit.data(), nit_dev_, B * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H");
+    std::vector<double> rec(B * (size_t)max_iterations_ * rec_);
+    records_.Download(rec.data(), rec.size());
+    for (size_t b = 0; b < B; ++b) {
+      if (nit[b] != iterations_done_ + 1) continue;   // this problem did not take part in the iteration that just ended
+      const double* r = rec.data() + (b * max_iterations_ + iterations_done_) * rec_;
+      if (std::isnan(r[1])) continue;
+      if (!user_exit_((int64_t)b, Record(r, iterations_done_))) flags[b] = 1;
+    }
+    exit_flags_.Upload(flags.data(), B);
+    ++iterations_done_;
+  }
   int n_, m_r_, k_, m_;
   int64_t batch_;
   HostResiduals residuals_;
+  Retraction retraction_;
+  UserExitCallback user_exit_;
+  detail::DeviceBuffer<double> step_, step_alpha_, records_;
+  detail::DeviceBuffer<int32_t> exit_flags_;
+  std::vector<double> h_step_, h_alpha_;
+  std::vector<NLSSolverOutputs> outputs_;
+  int rec_{0}, max_iterations_{1}, iterations_done_{0};
+  int32_t* term_dev_{nullptr}; int32_t* nit_dev_{nullptr};
   mo_plan* plan_{nullptr};
   detail::DeviceBuffer<double> vars_, cand_, J_, r_, r_cand_, Jeq_, req_, req_cand_, ca_, cb_;
   detail::DeviceBuffer<int32_t> cv_;
   std::vector<double> h_x_, h_J_, h_r_, h_Jeq_, h_JeqT_, h_req_, variables_;
   std::vector<int32_t> num_iterations_;
   std::exception_ptr callback_error_{nullptr};
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mini_opt::Residual / MakeResidual / Problem / ConstrainedNonlinearLeastSquares (residual.hpp:28-143, nonlinear.hpp:33-52, 127-230)
+// as a drop-in: the same functor shape -- ResidualType(const ParamType&, JacobianType* J_or_null) on the residual's OWN parameters,
+// picked out of the full vector by an index list -- evaluated on the host like the reference's, with the per-residual Jacobians
+// scattered into the dense stacks the device consumes (UpdateJacobian's J_out.col(index[l]) = J.col(l), residual.hpp:230-250; summing
+// J^T J over residuals, residual.hpp:206-224, is the J^T J of the stacked rows).  With Eigen on the include path ParamType / ResidualType
+// / JacobianType ARE the reference's Eigen types (functors compile unchanged; not exercised in this image, which has no Eigen);
+// without it they are the small fixed-size types below.
+constexpr int Dynamic = -1;
+#ifdef MINI_OPT_HIP_HAS_EIGEN
+template <int N> using VectorN = Eigen::Matrix<double, N, 1>;
+template <int R, int P> using JacobianRP = Eigen::Matrix<double, R, P>;
+#else
+template <int N> struct VectorN {
+  std::array<double, (size_t)N> v{};
+  double& operator[](int i) { return v[(size_t)i]; }
+  double operator[](int i) const { return v[(size_t)i]; }
+  double& operator()(int i) { return v[(size_t)i]; }
+  double operator()(int i) const { return v[(size_t)i]; }
+  int rows() const { return N; }
+  int size() const { return N; }
+  const double* data() const { return v.data(); }
+  double* data() { return v.data(); }
+};
+template <> struct VectorN<Dynamic> {
+  std::vector<double> v;
+  VectorN() = default;
+  explicit VectorN(int n) : v((size_t)n, 0.0) {}
+  double& operator[](int i) { return v[(size_t)i]; }
+  double operator[](int i) const { return v[(size_t)i]; }
+  double& operator()(int i) { return v[(size_t)i]; }
+  double operator()(int i) const { return v[(size_t)i]; }
+  int rows() const { return (int)v.size(); }
+  int size() const { return (int)v.size(); }
+  const double* data() const { return v.data(); }
+  double* data() { return v.data(); }
+};
+template <int R, int P> struct JacobianRP {   // column-major like Eigen's fixed-size matrices
+  std::vector<double> a = std::vector<double>((size_t)R * (size_t)(P > 0 ? P : 0), 0.0);
+  int cols_{P > 0 ? P : 0};
+  void resize(int rows, int cols) { (void)rows; cols_ = cols; a.assign((size_t)R * (size_t)cols, 0.0); }
+  double& operator()(int r, int c) { return a[(size_t)r + (size_t)c * R]; }
+  double operator()(int r, int c) const { return a[(size_t)r + (size_t)c * R]; }
+  int rows() const { return R; }
+  int cols() const { return cols_; }
+  void setZero() { std::fill(a.begin(), a.end(), 0.0); }
+};
+#endif
+
+class Residual final {   // residual.hpp:28-117
+ public:
+  int Dimension() const { return impl_->Dimension(); }
+  // h(x) into b_out[0 .. Dimension())
+  void ErrorVector(const double* params, double* b_out) const { impl_->Evaluate(params, b_out, nullptr, 0); }
+  // rows of the dense stack: J_out is Dimension() x n ROW-major with leading dimension ld (zeroed by the caller), b_out = h(x)
+  void UpdateJacobian(const double* params, double* J_out, int ld, double* b_out) const { impl_->Evaluate(params, b_out, J_out, ld); }
+  double QuadraticError(const std::vector<double>& params) const {   // 0.5 |h|^2, residual.cc
+    std::vector<double> b((size_t)Dimension());
+    ErrorVector(params.data(), b.data());
+    double s = 0; for (double v : b) s += v * v;
+    return 0.5 * s;
+  }
+  struct Concept {
+    virtual ~Concept() = default;
+    virtual int Dimension() const noexcept = 0;
+    virtual void Evaluate(const double* params, double* b_out, double* J_out, int ld) const = 0;
+  };
+  explicit Residual(std::unique_ptr<Concept> impl) noexcept : impl_(std::move(impl)) {}
+ private:
+  std::unique_ptr<Concept> impl_;
+};
+
+namespace detail {
+template <int R, int P, typename F> class ResidualModel final : public Residual::Concept {   // Residual::Model, residual.hpp:88-111
+ public:
+  ResidualModel(std::vector<int> index, F func) : index_(std::move(index)), func_(std::move(func)) {}
+  int Dimension() const noexcept override { return R; }
+  void Evaluate(const double* params, double* b_out, double* J_out, int ld) const override {
+    const int np = (int)index_.size();
+    auto local = MakeParams(np);
+    for (int l = 0; l < np; ++l) local[l] = params[index_[(size_t)l]];   // GatherParams, residual.hpp:150-163
+    if (!J_out) {
+      const auto r = func_(local, static_cast<JacobianRP<R, P>*>(nullptr));
+      for (int i = 0; i < R; ++i) b_out[i] = r[i];
+      return;
+    }
+    JacobianRP<R, P> J;
+    if constexpr (P == Dynamic) J.resize(R, np);
+    const auto r = func_(local, &J);
+    for (int i = 0; i < R; ++i) {
+      b_out[i] = r[i];
+      for (int l = 0; l < np; ++l) J_out[(size_t)i * ld + index_[(size_t)l]] = J(i, l);   // J_out.col(index[l]) = J.col(l), residual.hpp:240-246
+    }
+  }
+ private:
+  static VectorN<P> MakeParams(int np) { if constexpr (P == Dynamic) return VectorN<P>(np); else { (void)np; return VectorN<P>(); } }
+  std::vector<int> index_;
+  F func_;
+};
+}  // namespace detail
+
+// MakeResidual<R, P>({indices...}, functor), residual.hpp:119-143.
+template <int R, int P, typename F> Residual MakeResidual(std::initializer_list<int> index, F&& func) {
+  using FuncType = std::remove_const_t<std::remove_reference_t<F>>;
+  if (P != Dynamic && (int)index.size() != P) throw default_error("MakeResidual: index list does not have P entries");
+  return Residual(std::make_unique<detail::ResidualModel<R, P, FuncType>>(std::vector<int>(index), std::forward<F>(func)));
+}
+
+struct Problem {   // nonlinear.hpp:33-52
+  int dimension{0};
+  std::vector<Residual> costs;
+  std::vector<LinearInequalityConstraint> inequality_constraints;
+  std::vector<Residual> equality_constraints;
+};
+
+// Drop-in for mini_opt::ConstrainedNonlinearLeastSquares (nonlinear.hpp:127-230) on ONE problem given as Residuals -- or on `batch`
+// initial guesses of it at once (Solve takes batch x dimension values), which is what the device is for.
+class ConstrainedNonlinearLeastSquares {
+ public:
+  using Params = BatchedConstrainedNonlinearLeastSquares::Params;
+  using Retraction = BatchedConstrainedNonlinearLeastSquares::Retraction;
+  explicit ConstrainedNonlinearLeastSquares(const Problem* problem, Retraction retraction = nullptr, int64_t batch = 1, int device = 0) : p_(problem) {
+    if (!p_) throw default_error("Must have a valid problem");   // F_ASSERT nonlinear.cc:21
+    int m_r = 0, k = 0;
+    for (const auto& c : p_->costs) m_r += c.Dimension();
+    for (const auto& c : p_->equality_constraints) k += c.Dimension();
+    const int n = p_->dimension;
+    auto eval = [this, n, m_r, k](const double* x, int64_t B, double* r, double* J, double* r_eq, double* J_eq) {
+      for (int64_t b = 0; b < B; ++b) {
+        const double* xb = x + (size_t)b * n;
+        double* rb = r + (size_t)b * m_r; double* Jb = J ? J + (size_t)b * m_r * n : nullptr;
+        if (Jb) std::fill(Jb, Jb + (size_t)m_r * n, 0.0);
+        int row = 0;
+        for (const auto& c : p_->costs) {
+          if (Jb) c.UpdateJacobian(xb, Jb + (size_t)row * n, n, rb + row); else c.ErrorVector(xb, rb + row);
+          row += c.Dimension();
+        }
+        if (!k) continue;
+        double* qb = r_eq + (size_t)b * k; double* Qb = J_eq ? J_eq + (size_t)b * k * n : nullptr;
+        if (Qb) std::fill(Qb, Qb + (size_t)k * n, 0.0);
+        row = 0;
+        for (const auto& c : p_->equality_constraints) {
+          if (Qb) c.UpdateJacobian(xb, Qb + (size_t)row * n, n, qb + row); else c.ErrorVector(xb, qb + row);
+          row += c.Dimension();
+        }
+      }
+    };
+    impl_ = std::make_unique<BatchedConstrainedNonlinearLeastSquares>(n, m_r, k, p_->inequality_constraints, eval, batch, device);
+    if (retraction) impl_->SetRetraction(std::move(retraction));
+  }
+  // Solve(params, variables), nonlinear.cc:75-158; for batch > 1 the outputs of problem b are outputs()[b]
+  NLSSolverOutputs Solve(const Params& params, const std::vector<double>& variables) {
+    (void)impl_->Solve(params, variables);
+    return impl_->outputs().front();
+  }
+  const std::vector<NLSSolverOutputs>& outputs() const { return impl_->outputs(); }
+  const std::vector<double>& variables() const { return impl_->variables(); }
+  void SetUserExitCallback(std::function<bool(const NLSIteration&)> cb) {   // nonlinear.hpp:157
+    if (!cb) { impl_->SetUserExitCallback(nullptr); return; }
+    impl_->SetUserExitCallback([cb](int64_t, const NLSIteration& it) { return cb(it); });
+  }
+ private:
+  const Problem* p_;
+  std::unique_ptr<BatchedConstrainedNonlinearLeastSquares> impl_;
 };
 
 }  // namespace mini_opt_hip

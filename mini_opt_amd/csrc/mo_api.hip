@@ -678,9 +678,13 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
       MO_HIP_CHECK(hipMemsetAsync(qp_term, 0, sizeof(int) * (size_t)batch, s));
       MO_HIP_CHECK(hipMemsetAsync(qp_nit, 0, sizeof(int) * (size_t)batch, s));
       MO_HIP_CHECK(mo::launch_nullspace(ka, d.dtype, plan->num_cus, s));
-    } else if (int rc = qp_solve_impl(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, nullptr, lagrange, qp_status,
-                                      si + mo::NLS_SI_TERM, mo::NLS_SI, stream)) {
-      return rc;  // terminated problems are skipped
+    } else {
+      void* qp_records = np->qp_iterations ? (void*)((double*)np->qp_iterations + (size_t)iter * (size_t)batch * sp.max_iterations * MO_ITER_RECORD) : nullptr;
+      if (int rc = qp_solve_impl(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, qp_records, lagrange, qp_status,
+                                 si + mo::NLS_SI_TERM, mo::NLS_SI, stream)) return rc;  // terminated problems are skipped
+      if (np->qp_lagrange && k > 0)
+        MO_HIP_CHECK(hipMemcpyAsync((double*)np->qp_lagrange + (size_t)iter * (size_t)batch * 2, lagrange, sizeof(double) * 2 * (size_t)batch,
+                                    hipMemcpyDeviceToDevice, s));
     }
     MO_HIP_CHECK(mo::launch_cost_derivative(da, d.dtype, s));
     MO_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));

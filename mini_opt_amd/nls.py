@@ -127,6 +127,44 @@ class DeviceFamily:
 
 
 @dataclass
+class Residual:
+    """mini_opt::Residual as MakeResidual<R, P>(index, functor) builds it (residual.hpp:28-143): `fn(params [B, P], want_J) ->
+    (r [B, R], J [B, R, P] | None)` sees only the residual's own parameters, picked out of the full vector by `index`."""
+    index: Sequence[int]
+    fn: ResidualFn
+    rows: int
+
+    def Dimension(self) -> int:
+        return self.rows
+
+    def QuadraticError(self, params: torch.Tensor) -> torch.Tensor:
+        r, _ = self.fn(params[:, list(self.index)], False)
+        return 0.5 * (r * r).sum(dim=1)
+
+
+def MakeResidual(index: Sequence[int], fn: ResidualFn, rows: int) -> Residual:
+    return Residual(tuple(int(i) for i in index), fn, int(rows))
+
+
+def stack_residuals(residuals: Sequence[Residual], n: int) -> ResidualFn:
+    """The dense stack of a list of Residuals: values concatenated, every residual's Jacobian columns scattered to its index list
+    (UpdateJacobian's J_out.col(index[l]) = J.col(l), residual.hpp:230-250; summing J^T J over residuals, residual.hpp:206-224, is the
+    J^T J of the stacked rows)."""
+    def fn(x, want_J):
+        rs, Js = [], []
+        for res in residuals:
+            idx = torch.as_tensor(list(res.index), dtype=torch.long, device=x.device)
+            r, Jl = res.fn(x.index_select(1, idx), want_J)
+            rs.append(r)
+            if want_J:
+                J = torch.zeros(x.shape[0], res.rows, n, dtype=x.dtype, device=x.device)
+                J.index_copy_(2, idx, Jl)
+                Js.append(J)
+        return torch.cat(rs, dim=1), (torch.cat(Js, dim=1) if want_J else None)
+    return fn
+
+
+@dataclass
 class Problem:
     """mini_opt::Problem (nonlinear.hpp:33-52) for a batch of independent problems sharing one structure."""
     dimension: int
@@ -136,6 +174,14 @@ class Problem:
     equality_rows: int = 0                          # k
     inequality_constraints: Sequence[Tuple[int, float, float]] = field(default_factory=list)  # (variable, a, b): a x + b >= 0
 
+    @staticmethod
+    def FromResiduals(dimension: int, costs: Sequence[Residual], equality_constraints: Sequence[Residual] = (),
+                      inequality_constraints: Sequence[Tuple[int, float, float]] = ()) -> "Problem":
+        """The reference's own shape: Problem{costs, inequality_constraints, equality_constraints, dimension} of Residuals."""
+        k = sum(r.rows for r in equality_constraints)
+        return Problem(dimension, stack_residuals(costs, dimension), sum(r.rows for r in costs),
+                       stack_residuals(equality_constraints, dimension) if k else None, k, list(inequality_constraints))
+
 
 @dataclass
 class NLSSolverOutputs:
@@ -144,6 +190,9 @@ class NLSSolverOutputs:
     num_iterations: torch.Tensor     # [B] int32
     iterations: torch.Tensor         # [B, max_iterations, 12 + 3 (max_line_search_iterations + 1)] NLSIteration records
     status: torch.Tensor             # [B] int32 QP status of a problem that ended with QP_FAILURE
+    qp_iterations: Optional[torch.Tensor] = None   # [max_iterations, B, max_qp_iterations, 14] QPInteriorPointIteration records (on request)
+    qp_lagrange: Optional[torch.Tensor] = None     # [max_iterations, B, 2] {min, l_infinity} of each QP's multipliers (k > 0, on request)
+    null_space_path: bool = False                  # equality-only problems: the QP of every iteration is QPNullSpaceSolver's
 
     def NumQPIterations(self) -> torch.Tensor:
         it = torch.nan_to_num(self.iterations[:, :, 10], nan=0.0)
@@ -270,8 +319,9 @@ class ConstrainedNonlinearLeastSquares:
             p.user_exit = _ptr(self.user_exit_)
         return p
 
-    def Solve(self, params: Params, variables: torch.Tensor) -> NLSSolverOutputs:
-        """nonlinear.cc:75-158 for every problem of the batch."""
+    def Solve(self, params: Params, variables: torch.Tensor, record_qp_iterations: bool = False) -> NLSSolverOutputs:
+        """nonlinear.cc:75-158 for every problem of the batch.  record_qp_iterations keeps every QP's QPInteriorPointIteration records
+        (NLSIteration::qp_outputs) for mini_opt_amd.serialization."""
         if tuple(variables.shape) != (self.batch, self.n):
             raise L.MiniOptError(-2, f"variables must be [{self.batch}, {self.n}]")
         self.variables_.copy_(variables)
@@ -284,16 +334,25 @@ class ConstrainedNonlinearLeastSquares:
         its = torch.full((B, max(params.max_iterations, 1), rec), float("nan"), dtype=torch.float64, device=dev)
         sp = params.as_struct(self._retract_code)
         prob = self._problem_struct()
+        qp_its = qp_lag = None
+        if record_qp_iterations:
+            qp_its = torch.full((max(params.max_iterations, 1), B, max(params.max_qp_iterations, 1), L.MO_ITER_RECORD), float("nan"),
+                                dtype=torch.float64, device=dev)
+            prob.qp_iterations = _ptr(qp_its)
+            if self.k:
+                qp_lag = torch.full((max(params.max_iterations, 1), B, 2), float("nan"), dtype=torch.float64, device=dev)
+                prob.qp_lagrange = _ptr(qp_lag)
         self._callback_error = None
         self._iter_done = 0
-        self._outputs_view = NLSSolverOutputs(term, nit, its, status)
+        null_path = self.m == 0 and self.k > 0
+        self._outputs_view = NLSSolverOutputs(term, nit, its, status, qp_its, qp_lag, null_path)
         cb = L.NLS_EVAL_FN(self._eval)
         rc = L.lib().mo_nls_solve(self._plan.h, C.byref(prob), B, C.byref(sp), cb, None, _ptr(term), _ptr(nit), _ptr(its),
                                   _ptr(status), _stream())
         if self._callback_error is not None:
             raise self._callback_error
         L.check(rc)
-        return NLSSolverOutputs(term, nit, its, status)
+        return self._outputs_view
 
     def variables(self) -> torch.Tensor:
         return self.variables_

@@ -249,6 +249,92 @@ static void TestNlsDeviceResiduals() {
   mo_plan_destroy(plan);
 }
 
+// mini_opt::Problem built from MakeResidual<R, P>(index, functor) residuals (residual.hpp:119-143, nonlinear.hpp:33-52) through the
+// drop-in ConstrainedNonlinearLeastSquares: TestRosenbrock (nonlinear_test.cc:390-430) with the reference's functor shape, the sphere
+// with two product equalities on different index pairs (nonlinear_test.cc:722-826: the scatter of per-residual Jacobians into the
+// dense stack), a custom Retraction and SetUserExitCallback.
+static void TestProblemOfResiduals() {
+  const double sb = std::sqrt(100.0);
+  auto rosenbrock = [sb](const VectorN<2>& x, JacobianRP<2, 2>* J) -> VectorN<2> {
+    if (J) { (*J)(0, 0) = -1.0; (*J)(0, 1) = 0.0; (*J)(1, 0) = -2.0 * x[0] * sb; (*J)(1, 1) = sb; }
+    VectorN<2> r; r[0] = 1.0 - x[0]; r[1] = sb * (x[1] - x[0] * x[0]);
+    return r;
+  };
+  Problem problem{};
+  problem.dimension = 2;
+  problem.costs.push_back(MakeResidual<2, 2>({0, 1}, rosenbrock));
+  EXPECT_TRUE(problem.costs[0].Dimension() == 2);
+  EXPECT_NEAR(0.5 * (16.0 + 100.0 * 4.0), problem.costs[0].QuadraticError({-3.0, 7.0}), 1e-12);
+  ConstrainedNonlinearLeastSquares nls(&problem);
+  ConstrainedNonlinearLeastSquares::Params p{};
+  p.max_iterations = 5; p.max_qp_iterations = 1;
+  const NLSSolverOutputs out = nls.Solve(p, {-5.0, -3.0});
+  EXPECT_TRUE(out.termination_state == NLSTerminationState::SATISFIED_ABSOLUTE_TOL);
+  EXPECT_NEAR(1.0, nls.variables()[0], 1e-6); EXPECT_NEAR(1.0, nls.variables()[1], 1e-6);
+  EXPECT_TRUE(!out.iterations.empty() && out.iterations.size() <= 5);
+  EXPECT_TRUE(out.iterations.front().iteration == 0 && out.iterations.front().errors_initial.f > 100.0);
+  EXPECT_TRUE(out.NumLineSearchSteps() >= (int)out.iterations.size());
+
+  // sphere: one 6-dimensional cost, two scalar equality residuals on index pairs {0, 1} and {2, 3}; a Dynamic-sized residual on {4, 5}
+  auto sphere = [](const VectorN<6>& x, JacobianRP<6, 6>* J) -> VectorN<6> {
+    if (J) { J->setZero(); for (int i = 0; i < 6; ++i) (*J)(i, i) = 1.0; }
+    return x;
+  };
+  auto product = [](double target) {
+    return [target](const VectorN<2>& x, JacobianRP<1, 2>* J) -> VectorN<1> {
+      if (J) { (*J)(0, 0) = x[1]; (*J)(0, 1) = x[0]; }
+      VectorN<1> r; r[0] = x[0] * x[1] - target;
+      return r;
+    };
+  };
+  auto tail = [](const VectorN<Dynamic>& x, JacobianRP<1, Dynamic>* J) -> VectorN<1> {
+    if (J) { (*J)(0, 0) = 1.0; (*J)(0, 1) = -1.0; }
+    VectorN<1> r; r[0] = x[0] - x[1];
+    return r;
+  };
+  Problem sp{};
+  sp.dimension = 6;
+  sp.costs.push_back(MakeResidual<6, 6>({0, 1, 2, 3, 4, 5}, sphere));
+  sp.costs.push_back(MakeResidual<1, Dynamic>({4, 5}, tail));
+  sp.equality_constraints.push_back(MakeResidual<1, 2>({0, 1}, product(4.0)));
+  sp.equality_constraints.push_back(MakeResidual<1, 2>({2, 3}, product(9.0)));
+  ConstrainedNonlinearLeastSquares snls(&sp, nullptr, 2);
+  ConstrainedNonlinearLeastSquares::Params q{};
+  q.max_iterations = 100; q.max_qp_iterations = 1; q.relative_exit_tol = 1e-12; q.absolute_first_derivative_tol = 1e-9;
+  q.termination_kkt_tolerance = 1e-6; q.lambda_initial = 0.001;
+  (void)snls.Solve(q, {5.0, 3.0, -7.0, -2.0, 4.0, -9.0,   -12.0, -1.5, 20.0, 6.0, -3.0, 8.0});
+  for (int b = 0; b < 2; ++b) {
+    const double* v = snls.variables().data() + 6 * b;
+    const auto t = snls.outputs()[(size_t)b].termination_state;
+    EXPECT_TRUE(t == NLSTerminationState::SATISFIED_ABSOLUTE_TOL || t == NLSTerminationState::SATISFIED_RELATIVE_TOL ||
+                t == NLSTerminationState::SATISFIED_FIRST_ORDER_TOL);
+    EXPECT_NEAR(2.0, std::fabs(v[0]), 5e-5); EXPECT_NEAR(v[0], v[1], 5e-5);
+    EXPECT_NEAR(3.0, std::fabs(v[2]), 5e-5); EXPECT_NEAR(v[2], v[3], 5e-5);
+    EXPECT_NEAR(0.0, v[4], 5e-5); EXPECT_NEAR(0.0, v[5], 5e-5);
+  }
+
+  // custom Retraction (nonlinear.hpp:127): the plain x + alpha dx written by the caller gives the built-in's result; it is really called
+  int retractions = 0;
+  ConstrainedNonlinearLeastSquares rnls(&problem, [&retractions](std::vector<double>& x, const VectorBlock& dx, double alpha) {
+    ++retractions;
+    for (size_t i = 0; i < x.size(); ++i) x[i] += dx[(int)i] * alpha;
+  });
+  const NLSSolverOutputs rout = rnls.Solve(p, {-5.0, -3.0});
+  EXPECT_TRUE(retractions >= (int)rout.iterations.size() && retractions > 0);
+  EXPECT_TRUE(rout.termination_state == out.termination_state && rout.iterations.size() == out.iterations.size());
+  EXPECT_NEAR(nls.variables()[0], rnls.variables()[0], 1e-12); EXPECT_NEAR(nls.variables()[1], rnls.variables()[1], 1e-12);
+
+  // SetUserExitCallback (nonlinear.hpp:157): stop after the first iteration
+  int calls = 0;
+  nls.SetUserExitCallback([&calls](const NLSIteration& it) { ++calls; return it.iteration < 0; });
+  const NLSSolverOutputs uout = nls.Solve(p, {-5.0, -3.0});
+  EXPECT_TRUE(uout.termination_state == NLSTerminationState::USER_CALLBACK && uout.iterations.size() == 1 && calls == 1);
+  nls.SetUserExitCallback(nullptr);
+  bool threw = false;
+  try { (void)MakeResidual<2, 2>({0}, rosenbrock); } catch (const default_error&) { threw = true; }   // F_ASSERT_EQ residual.hpp:137
+  EXPECT_TRUE(threw);
+}
+
 int main() {
   TestLinearInequalityConstraint();
   TestEliminationAllConstraints();
@@ -258,6 +344,7 @@ int main() {
   TestNlsRosenbrock();
   TestNlsSphereWithEqualities();
   TestNlsDeviceResiduals();
+  TestProblemOfResiduals();
   if (g_fail) { std::printf("%d FAILURES\n", g_fail); return 1; }
   std::printf("facade_test: all tests passed\n");
   return 0;

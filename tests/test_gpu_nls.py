@@ -566,3 +566,71 @@ def test_user_exit_callback_on_device():
     nls.SetUserExitCallback(None)
     out3 = nls.Solve(NLS.Params(max_iterations=10, max_qp_iterations=1), T(guesses))
     assert torch.equal(out2.termination_state, out3.termination_state) and torch.equal(out2.num_iterations, out3.num_iterations)
+
+
+# ---- f3 leftovers: the reference's JSON form of NLSSolverOutputs, Problems made of Residuals -------------------------------------------
+def test_json_serialization_of_batched_outputs():
+    """mini_opt_amd.serialization writes the reference's schema (source/serialization.cc:32-136): keys, enum strings, one QP record per
+    interior-point iteration; the numbers are the oracle's logs."""
+    import json
+    from mini_opt_amd import serialization as S
+    guesses = np.array(P.ROSENBROCK_CONSTRAINED_GUESSES, dtype=float)
+    cons = [(0, 1.0, -1.2), (1, -1.0, 0.5)]
+    nls = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(2, P.rosenbrock_torch, cost_rows=2, inequality_constraints=cons), batch=len(guesses))
+    prm = dict(max_iterations=10, max_qp_iterations=10)
+    out = nls.Solve(NLS.Params(**prm), T(guesses), record_qp_iterations=True)
+    for p, g in enumerate(guesses):
+        doc = json.loads(S.dumps(out, p))
+        assert set(doc) == {"termination_state", "iterations"} and doc["termination_state"] == S.NLS_TERMINATION[int(out.termination_state[p])]
+        o = N.ConstrainedNonlinearLeastSquares(N.Problem(2, P.rosenbrock_np, inequality_constraints=cons))
+        _, logs = o.solve(N.Params(**prm), g)
+        assert len(doc["iterations"]) == len(logs) == int(out.num_iterations[p])
+        for i, (it, log) in enumerate(zip(doc["iterations"], logs)):
+            assert set(it) == {"iteration", "optimizer_state", "lambda", "errors_initial", "qp_outputs", "qp_eigenvalues",
+                               "directional_derivatives", "penalty", "step_result", "line_search_steps"}
+            assert it["iteration"] == i and it["qp_eigenvalues"] is None and it["optimizer_state"] in S.OPTIMIZER_STATE
+            assert it["step_result"] == S.STEP_RESULT[log.step_result]
+            np.testing.assert_allclose(it["errors_initial"]["f"], log.errors_pre.f, rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(it["directional_derivatives"]["d_f"], log.d_f, rtol=1e-5, atol=1e-9)
+            assert len(it["line_search_steps"]) == len(log.steps)
+            qp = it["qp_outputs"]
+            assert set(qp) == {"termination_state", "iterations", "lagrange_multipliers"} and qp["lagrange_multipliers"] is None
+            assert qp["termination_state"] in S.QP_TERMINATION and len(qp["iterations"]) == log.qp_iterations
+            for q in qp["iterations"]:
+                assert set(q) == {"kkt_initial", "kkt_final", "ip_outputs"} and set(q["kkt_final"]) == {"r_dual", "r_comp", "r_primal_eq", "r_primal_ineq"}
+                assert set(q["ip_outputs"]) == {"mu", "alpha", "alpha_probe", "mu_affine"} and q["ip_outputs"]["mu_affine"] is None
+    # equality-only problems: qp_outputs is the null-space solver's state (serialization.cc:89-101)
+    spec = P.TWO_ANGLE
+    prob = NLS.Problem(2, _chain_family(spec, spec["cost_rows"]), cost_rows=1, equality=_chain_family(spec, spec["eq_rows"]), equality_rows=1)
+    cn = NLS.ConstrainedNonlinearLeastSquares(prob, batch=2, retraction=NLS.WRAP_PI)
+    o2 = cn.Solve(NLS.Params(**spec["params"]), T(np.array([[0.3, 0.2], [1.0, -0.5]])))
+    doc = S.nls_outputs_to_json(o2, 1)
+    assert doc["iterations"] and all(it["qp_outputs"] == "SUCCESS" for it in doc["iterations"])
+    json.dumps(doc)
+
+
+def test_problem_of_residuals_matches_the_dense_stack():
+    """Problem.FromResiduals / MakeResidual (residual.hpp:119-143, nonlinear.hpp:33-52): per-residual functors on their own parameters,
+    Jacobians scattered by the index lists -- the sphere with its two product equalities (nonlinear_test.cc:722-826) gives exactly the
+    results of the hand-stacked version."""
+    def sphere(x, want_J):
+        return x.clone(), (torch.eye(6, dtype=x.dtype, device=x.device).expand(x.shape[0], 6, 6).contiguous() if want_J else None)
+
+    def product(target):
+        def fn(x, want_J):
+            r = (x[:, 0] * x[:, 1] - target).unsqueeze(1)
+            J = torch.stack([x[:, 1], x[:, 0]], dim=1).unsqueeze(1) if want_J else None
+            return r, J
+        return fn
+    guesses = np.array(P.sphere_guesses(12))
+    prm = NLS.Params(max_iterations=100, max_qp_iterations=1, relative_exit_tol=1e-12, absolute_first_derivative_tol=1e-9,
+                     termination_kkt_tolerance=1e-6, lambda_initial=0.001)
+    a = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem.FromResiduals(
+        6, [NLS.MakeResidual(range(6), sphere, 6)], [NLS.MakeResidual((0, 1), product(4.0), 1), NLS.MakeResidual((2, 3), product(9.0), 1)]), batch=12)
+    b = NLS.ConstrainedNonlinearLeastSquares(NLS.Problem(6, P.sphere_torch, cost_rows=6, equality=P.sphere_eq_torch, equality_rows=2), batch=12)
+    oa, ob = a.Solve(prm, T(guesses)), b.Solve(prm, T(guesses))
+    assert torch.equal(oa.termination_state, ob.termination_state) and torch.equal(oa.num_iterations, ob.num_iterations)
+    assert torch.equal(a.variables(), b.variables())
+    res = NLS.MakeResidual((2, 3), product(9.0), 1)
+    assert res.Dimension() == 1
+    np.testing.assert_allclose(res.QuadraticError(T(guesses)).cpu().numpy(), 0.5 * (guesses[:, 2] * guesses[:, 3] - 9.0) ** 2, rtol=1e-14)
