@@ -401,6 +401,78 @@ __device__ inline void sweep_step_lean(d4& T, double& bad, int g, int j) {
   masked_set<mrow>(rowk_new, rk);
   T[src_t] = rowk_new;
 }
+// ---- the fused-broadcast sweep (SW == 5) --------------------------------------------------------------------------------------
+// v_fmac_f64 has a DPP form on gfx950 (VOP2), and row_newbcast may read the destination register itself (tools/dpp_fmac.hip checks it
+// bit for bit):  T[t] <- T[t] - T[t](row lane K) * rk  is ONE instruction where the lean sweep spends a v_mov_b64_dpp and a v_fma_f64.
+// The pivot column cannot ride along (its lanes ARE the broadcast source): rk is zeroed there for the fused update and the column is
+// scaled by 1/d afterwards under an EXEC mask.  The pivot check moves to the scalar unit: d passes through SGPRs anyway (v_readlane), so
+// "zero" and "not finite" are integer tests on its bits, accumulated as a running min / max -- no VALU instruction at all.
+template <unsigned long long MASK> __device__ inline void masked_zero1(double& v) {  // v = 0 in the lanes of MASK
+  unsigned long long save;
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b64 %[d], 0\n\t"
+               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               : [d] "+v"(v), [sv] "=&s"(save)
+               : [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
+}
+template <unsigned long long MASK> __device__ inline void masked_mul4(d4& T, double f) {  // T[0..3] *= f in the lanes of MASK
+  unsigned long long save;
+  double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mul_f64 %[a], %[a], %[f]\n\tv_mul_f64 %[b], %[b], %[f]\n\t"
+      "v_mul_f64 %[c], %[c], %[f]\n\tv_mul_f64 %[d], %[d], %[f]\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+      : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3), [sv] "=&s"(save)
+      : [f] "v"(f), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
+  T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
+}
+template <int K> __device__ inline void fmac_bcast4(d4& T, double rk0) {  // T[t] -= T[t](lane K of the row) * rk0, t = 0..3
+  double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %[a], -%[a], %[r] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %[b], -%[b], %[r] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %[c], -%[c], %[r] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %[d], -%[d], %[r] row_newbcast:%[k] row_mask:0xf bank_mask:0xf"
+      : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3)
+      : [r] "v"(rk0), [k] "i"(K));
+  T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
+}
+struct PivotBits { unsigned min_mag, max_hi; };  // running min of the pivots' magnitude bits / max of their high words (scalar registers)
+template <int K>
+__device__ inline void sweep_step_fmac(d4& T, PivotBits& pb, int g, int j) {
+  constexpr int src_g = K & 3, src_t = K >> 2;
+  constexpr unsigned long long mcol = 0x0001000100010001ull << K;           // the four lanes of tile column k (j == K)
+  constexpr unsigned long long mrow = 0xFFFFull << (16 * src_g);            // the 16 lanes of the row group that holds row k
+  const double rowreg = T[src_t];  // every broadcast below is taken before any register of T is modified
+  const unsigned dlo = (unsigned)__builtin_amdgcn_readlane(__double2loint(rowreg), 16 * src_g + K);
+  const unsigned dhi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(rowreg), 16 * src_g + K);
+  const double d = __hiloint2double((int)dhi, (int)dlo);
+  {  // scalar unit: |d| == 0  <=>  mag == 0;  d not finite  <=>  (hi & 0x7fffffff) >= 0x7ff00000
+    const unsigned ahi = dhi & 0x7fffffffu;
+    const unsigned mag = ahi | (dlo >> 1) | (dlo & 1u);
+    pb.min_mag = mag < pb.min_mag ? mag : pb.min_mag;
+    pb.max_hi = ahi > pb.max_hi ? ahi : pb.max_hi;
+  }
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = fma(inv, fma(-d, inv, 1.0), inv);  // one Newton step: |inv d - 1| < 2e-15 (tools/microbench.hip)
+  double rk = bpermute_f64((16 * src_g + j) * 4, rowreg) * inv;  // T(k, j) / d for this lane's column j, in every row
+  double rk0 = rk;
+  masked_zero1<mcol>(rk0);           // the pivot column sits the fused update out
+  fmac_bcast4<K>(T, rk0);            // T(i, j) -= T(i, k) T(k, j) / d   (j != k)
+  masked_mul4<mcol>(T, inv);         // T(i, k) <- T(i, k) / d
+  masked_set_neg<mcol>(rk, inv);     // T(k, k) <- -1 / d
+  double rowk_new = T[src_t];
+  masked_set<mrow>(rowk_new, rk);    // row k <- T(k, j) / d
+  T[src_t] = rowk_new;
+}
+template <int K, int KEND> struct SweepLoopFmac {
+  static __device__ inline void run(d4& T, PivotBits& pb, int npiv, int g, int j) {
+    if (K < npiv) sweep_step_fmac<K>(T, pb, g, j);  // wave-uniform
+    SweepLoopFmac<K + 1, KEND>::run(T, pb, npiv, g, j);
+  }
+};
+template <int KEND> struct SweepLoopFmac<KEND, KEND> {
+  static __device__ inline void run(d4&, PivotBits&, int, int, int) {}
+};
 template <int K, int KEND, int SW> struct SweepLoop {
   static __device__ inline void run(d4& T, bool& ok, double& bad, int npiv, int g, int j) {
     if (K < npiv) {  // wave-uniform
@@ -414,6 +486,11 @@ template <int KEND, int SW> struct SweepLoop<KEND, KEND, SW> {
   static __device__ inline void run(d4&, bool&, double&, int, int, int) {}
 };
 template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int j) {
+  if (SW == 5) {
+    PivotBits pb{0xffffffffu, 0u};
+    SweepLoopFmac<0, 16>::run(T, pb, npiv, g, j);
+    return pb.min_mag != 0u && pb.max_hi < 0x7ff00000u;
+  }
   bool ok = true;
   double bad = 0.0;
   SweepLoop<0, 16, SW>::run(T, ok, bad, npiv, g, j);
@@ -586,6 +663,109 @@ __device__ inline bool block_eliminate(d4 (&U)[(NT + 1) * (NT + 1)], int k, int 
     }
   }
   return ok;
+}
+
+// ---- look-ahead elimination (SW == 6) ------------------------------------------------------------------------------------------
+// The diagonal sweeps are dependent VALU chains, the trailing updates independent MFMA chains; in program order "sweep, then all updates"
+// a wave alternates between a phase that can only wait on itself and a phase that only feeds the matrix pipe.  Here the update of block
+// step pa is split: the column of tile (pa+1, pa+1) first, then the sweep of that tile INTERLEAVED, pivot by pivot, with the remaining
+// updates of step pa (they touch neither that tile nor its operands) -- the classic look-ahead of dense factorisations, inside one
+// wavefront.  Same arithmetic, same order of operations per tile: results are bit-identical to block_eliminate.
+template <int NB> constexpr int la_count(int pa) { int c = 0; for (int pc = pa + 2; pc < NB; ++pc) c += 1 + (pc - pa); return c; }
+template <int NB> constexpr int la_pc(int pa, int idx) {
+  for (int pc = pa + 2; pc < NB; ++pc) { const int n = 1 + (pc - pa); if (idx < n) return pc; idx -= n; }
+  return -1;
+}
+template <int NB> constexpr int la_sub(int pa, int idx) {  // 0: the panel product -Z = (-T^-1) U_ac;  s >= 1: update of tile (pa + s, pc)
+  for (int pc = pa + 2; pc < NB; ++pc) { const int n = 1 + (pc - pa); if (idx < n) return idx; idx -= n; }
+  return -1;
+}
+// The Q-th of the four MFMAs of work item IDX of block step PA (an item = one 16x16x16 tile product = mfma4).
+template <int NT, int PA, int IDX, int Q> __device__ inline void la_mfma(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ) {
+  constexpr int NB = NT + 1;
+  if constexpr (IDX < la_count<NB>(PA)) {
+    constexpr int pc = la_pc<NB>(PA, IDX), sub = la_sub<NB>(PA, IDX);
+    if constexpr (sub == 0) {
+      if constexpr (Q == 0) negZ = d4{0.0, 0.0, 0.0, 0.0};
+      negZ = __builtin_amdgcn_mfma_f64_16x16x4f64(U[PA * NB + PA][Q], U[PA * NB + pc][Q], negZ, 0, 0, 0);
+    } else {
+      U[(PA + sub) * NB + pc] = __builtin_amdgcn_mfma_f64_16x16x4f64(U[PA * NB + (PA + sub)][Q], negZ[Q], U[(PA + sub) * NB + pc], 0, 0, 0);
+    }
+  }
+}
+// sweep_step_lean with the four MFMAs of one work item placed at the points where its dependent chain waits (in-order issue: an MFMA
+// behind the whole step would wait with it): behind the reciprocal's issue, behind the row broadcast's LDS request, behind the column
+// broadcasts, behind the rank-1 update.
+template <int NT, int PA, int K>
+__device__ inline void sweep_step_work(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ, double& bad, bool active, int g, int j) {
+  constexpr int NB = NT + 1;
+  constexpr int src_g = K & 3, src_t = K >> 2;
+  constexpr unsigned long long mcol = 0x0001000100010001ull << K;
+  constexpr unsigned long long mrow = 0xFFFFull << (16 * src_g);
+  d4& T = U[(PA + 1) * NB + (PA + 1)];
+  if (!active) {  // wave-uniform: pivots beyond the y tile's k rows -- only the work
+    la_mfma<NT, PA, K, 0>(U, negZ); la_mfma<NT, PA, K, 1>(U, negZ); la_mfma<NT, PA, K, 2>(U, negZ); la_mfma<NT, PA, K, 3>(U, negZ);
+    return;
+  }
+  const double rowreg = T[src_t];
+  const double d = readlane_f64(rowreg, 16 * src_g + K);
+  double inv = __builtin_amdgcn_rcp(d);
+  const double rowk = bpermute_f64((16 * src_g + j) * 4, rowreg);
+  __builtin_amdgcn_sched_barrier(0);
+  la_mfma<NT, PA, K, 0>(U, negZ);                       // covers v_rcp_f64 and the LDS round trip of the row broadcast
+  __builtin_amdgcn_sched_barrier(0);
+  inv = fma(inv, fma(-d, inv, 1.0), inv);
+  asm volatile("v_fma_f64 %0, %1, 0, %0" : "+v"(bad) : "v"(inv));
+  double f[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) f[t] = row_bcast64<K>(T[t]);
+  __builtin_amdgcn_sched_barrier(0);
+  la_mfma<NT, PA, K, 1>(U, negZ);
+  __builtin_amdgcn_sched_barrier(0);
+  double rk = rowk * inv;
+  masked_set_neg<mcol>(rk, inv);
+  masked_zero4<mcol>(T);
+  __builtin_amdgcn_sched_barrier(0);
+  la_mfma<NT, PA, K, 2>(U, negZ);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) T[t] = fma(-f[t], rk, T[t]);
+  double rowk_new = T[src_t];
+  masked_set<mrow>(rowk_new, rk);
+  T[src_t] = rowk_new;
+  __builtin_amdgcn_sched_barrier(0);
+  la_mfma<NT, PA, K, 3>(U, negZ);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int NT, int PA, int K> struct SweepWithWork {
+  static __device__ inline void run(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ, double& bad, int npiv, int g, int j) {
+    sweep_step_work<NT, PA, K>(U, negZ, bad, K < npiv, g, j);
+    SweepWithWork<NT, PA, K + 1>::run(U, negZ, bad, npiv, g, j);
+  }
+};
+template <int NT, int PA> struct SweepWithWork<NT, PA, 16> {
+  static __device__ inline void run(d4 (&)[(NT + 1) * (NT + 1)], d4&, double&, int, int, int) {
+    static_assert(la_count<NT + 1>(PA) <= 16, "one work item per pivot");
+  }
+};
+template <int NT, int PA> struct LookAheadSteps {
+  static __device__ inline void run(d4 (&U)[(NT + 1) * (NT + 1)], double& bad, int k, int g, int j) {
+    constexpr int NB = NT + 1;
+    // the column of the next diagonal tile first
+    d4 negZ = mfma4(U[PA * NB + PA], U[PA * NB + PA + 1], d4{0.0, 0.0, 0.0, 0.0});
+    U[(PA + 1) * NB + PA + 1] = mfma4(U[PA * NB + PA + 1], negZ, U[(PA + 1) * NB + PA + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    SweepWithWork<NT, PA, 0>::run(U, negZ, bad, PA + 1 < NT ? 16 : k, g, j);
+    if constexpr (PA + 2 < NB) LookAheadSteps<NT, PA + 1>::run(U, bad, k, g, j);
+  }
+};
+template <int NT>
+__device__ inline bool block_eliminate_lookahead(d4 (&U)[(NT + 1) * (NT + 1)], int k, int g, int j) {
+  const bool ok0 = sweep_tile<3>(U[0], 16, g, j);
+  __builtin_amdgcn_sched_barrier(0);
+  double bad = 0.0;
+  LookAheadSteps<NT, 0>::run(U, bad, k, g, j);
+  return ok0 && (bad == 0.0);
 }
 
 // Backward substitution after block_eliminate; xb[c] = solution at permuted position 16c + j (replicated over g),
@@ -896,6 +1076,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     // ---- P5: block elimination with 16x16 pivot blocks
     __builtin_amdgcn_sched_barrier(0);
     bool ok = true;
+    if constexpr (SW == 6) {
+      ok = block_eliminate_lookahead<NT>(U, k, g, j);
+    } else {
 #pragma unroll
     for (int pa = 0; pa < NB; ++pa) {
       ok = sweep_tile<SW>(U[pa * NB + pa], pa < NT ? 16 : k, g, j) && ok;
@@ -909,6 +1092,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
         __builtin_amdgcn_sched_barrier(0);  // one panel tile at a time: keeps a single -Z tile live (register pressure)
       }
       MO_STAMP(4);
+    }
     }
 
     __builtin_amdgcn_sched_barrier(0);
@@ -1698,7 +1882,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
   static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
   const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);  // measured best: 3 (A/B in DESIGN.md)
-  const int sw = (env_sw >= 0 && env_sw <= 3) ? env_sw : 3;
+  const int sw = (env_sw >= 0 && env_sw <= 6) ? env_sw : 3;
   long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
   const long long blocks_needed = (a.batch + 4 * wps - 1) / (4 * wps);
   if (grid > blocks_needed) grid = blocks_needed;
@@ -1815,9 +1999,19 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     return hipGetLastError();
   }
 #define MO_FUSED_LAUNCH(NT_, WPS_, SW_) hipLaunchKernelGGL((kkt_fused_f64_kernel<NT_, WPS_, SW_, false>), gd, bd, 0, stream, a)
+// MO_FUSED_SWEEP = 5 (fused-broadcast sweep) / 6 (look-ahead elimination): measured and rejected; they are only
+// instantiated in builds with -DMO_FUSED_EXPERIMENTS (A/B runs), the product build carries neither.
+#ifdef MO_FUSED_EXPERIMENTS
+#define MO_FUSED_EXPERIMENTAL(NT_, WPS_)              \
+    else if (sw == 5) MO_FUSED_LAUNCH(NT_, WPS_, 5);  \
+    else if (sw == 6) MO_FUSED_LAUNCH(NT_, WPS_, 6);
+#else
+#define MO_FUSED_EXPERIMENTAL(NT_, WPS_)
+#endif
 #define MO_FUSED_BY_SW(NT_, WPS_)                     \
   do {                                                \
     if (sw == 1) MO_FUSED_LAUNCH(NT_, WPS_, 1);       \
+    MO_FUSED_EXPERIMENTAL(NT_, WPS_)                  \
     else MO_FUSED_LAUNCH(NT_, WPS_, 3);               \
   } while (0)
   if (a.n > 32) {
