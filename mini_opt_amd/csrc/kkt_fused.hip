@@ -904,7 +904,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   const unsigned ring_base = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (low 32 bits of the flat address)
   const unsigned vec_base = ring_base + D * SLOT;                 // LDS byte address of xs
 
-  const int k = a.k, m = a.m, m_r = a.m_r;
+  // MO_STEP_NO_INEQUALITIES (SolveForUpdateNoInequalities, qp.cc:366-386): the constraints take no part (m = 0 below); the state and
+  // direction vectors keep their [x | s(m_lay) | y | z(m_lay)] layout, ds = dz = 0 and both step lengths are 1.
+  const int m_lay = a.m;
+  const bool no_ineq = (a.flags & MO_STEP_NO_INEQUALITIES) != 0;
+  const int k = a.k, m = no_ineq ? 0 : a.m, m_r = a.m_r;
   const int nn = a.n;  // actual number of variables <= N; the system is padded to whole tiles (unit diagonal, zero solution)
   // Once per wave: the ring (lanes whose J piece lies beyond the row never receive DMA data and must read zeros) and x's padding.
   for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       dma_doubles(vp + nn + m + k, vec_base + (3 * N + 3 * MCAP) * 8, m, lane);              // z
     }
     if (k > 0) {
-      dma_doubles(vp + nn + m, vec_base + (3 * N + 4 * MCAP + MCAP / 2) * 8, k, lane);       // y
+      dma_doubles(vp + nn + m_lay, vec_base + (3 * N + 4 * MCAP + MCAP / 2) * 8, k, lane);   // y
       dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 4 * MCAP + MCAP / 2 + 16) * 8, k, lane);  // b_eq
     }
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
@@ -1039,7 +1043,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       }
     }
     const bool slack_bad = __any(lane_bad_slack);
-    const bool any_bad_index = __any(lane_bad_index);
+    bool any_bad_index = __any(lane_bad_index);
+    if (no_ineq && m_lay > 0) {  // the index check of Setup (qp.cc:70-72) does not depend on the flag
+      bool bad = false;
+      const int* cvp = ka->cons_var + p * ka->cons_stride;
+      for (int ix = lane; ix < m_lay; ix += 64) { const int v = cvp[ix]; bad = bad || v < 0 || v >= nn; }
+      any_bad_index = __any(bad);
+    }
     lds_fence();
     double dS[NT], rS[NT];
     ldv<NT, QPL>(diagS, j, dS);
@@ -1149,7 +1159,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #pragma unroll
       for (int c = 0; c < NT; ++c) outv[c] = st == MO_STATUS_OK ? dxv[c] : nanv;
       stv_n<NT, QPL>(dp, j, nn, outv);
-      if (j < k) dp[nn + m + j] = st == MO_STATUS_OK ? dyv : nanv;
+      if (j < k) dp[nn + m_lay + j] = st == MO_STATUS_OK ? dyv : nanv;
+    }
+    if (no_ineq) {  // ds = dz = 0 (qp.cc:366-386 writes only dx, dy)
+      for (int ix = lane; ix < m_lay; ix += 64) { dp[nn + ix] = st == MO_STATUS_OK ? 0.0 : nanv; dp[nn + m_lay + k + ix] = st == MO_STATUS_OK ? 0.0 : nanv; }
     }
 #pragma unroll
     for (int ci = 0; ci < MC; ++ci) {
@@ -1378,7 +1391,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     for (int c = 0; c < NT; ++c) xv[c] = 0.0;
 #pragma unroll
     for (int ci = 0; ci < MC; ++ci) { cs[ci] = 1.0; cz[ci] = 1.0; }
-    const bool iterate_mode = a.mode == MODE_ITERATE;  // one Iterate (qp.cc:153-201) on the caller's state and mu
+    // MODE_RESIDUAL: EvaluateKKTConditions + ComputeErrors (qp.cc:391-437) on the caller's state -- part A of a pass, then the outputs
+    const bool residual_mode = a.mode == MODE_RESIDUAL;
+    const bool iterate_mode = a.mode == MODE_ITERATE || residual_mode;  // one Iterate (qp.cc:153-201) on the caller's state and mu
     if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
       ldv_n<NT, QPL>(vp, j, nn, xv);
       if (j < k) yv = vp[nn + m + j];
@@ -1469,7 +1484,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     double ip_mu = mu, probe_p = __builtin_nan(""), probe_d = __builtin_nan(""), mu_aff = __builtin_nan(""), mu_pc = 0.0;
 
     while (st == MO_STATUS_OK) {
-      const bool include_ineq = !guess_pass;
+      const bool include_ineq = !guess_pass && !(residual_mode && (a.flags & MO_STEP_NO_INEQUALITIES));
       // lane coordinates are re-made opaque every pass: nothing derived from them may be hoisted out of the pass loop and
       // kept in VGPRs across the factorisation (see the step kernel)
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
@@ -1603,6 +1618,24 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         n_rpi2 = wave_sum_f64(s_rpi2);
         n_rd2 = readlane_f64(n_rd2, 0); n_rpe2 = readlane_f64(n_rpe2, 0);  // uniform copies
       }
+      }
+      if (residual_mode) {  // r_ = [r_d | r_comp | r_pe | r_pi] (qp.cc:391-420) and the four norms of ComputeErrors (qp.cc:423-437)
+        double* ro = (double*)a.r_out + p * a.r_out_stride;
+        if (g == 0) {
+          stv_n<NT, QPL>(ro, j, nn, r_d);
+          if (j < k) ro[nn + m + j] = r_pe;
+        }
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci)
+          if (lane + 64 * ci < m) { ro[nn + lane + 64 * ci] = r_comp[ci]; ro[nn + m + k + lane + 64 * ci] = r_pi[ci]; }
+        if (a.kkt_out) {
+          double kq[4];
+          kkt_errors_sq(mu, kq);
+          if (!include_ineq) { kq[1] = 0.0; kq[3] = 0.0; }
+          const double e0 = sqrt(kq[0]), e1 = sqrt(kq[1]), e2 = sqrt(kq[2]), e3 = sqrt(kq[3]);
+          if (lane == 0) { double* ko = (double*)a.kkt_out + 4 * p; ko[0] = e0; ko[1] = e1; ko[2] = e2; ko[3] = e3; }
+        }
+        break;
       }
       if (!guess_pass && !iterate_mode) {
         // ---- the decision point of Solve (qp.cc:116-147)
@@ -1812,13 +1845,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     }
 
     // ---- outputs: state, termination, iteration count, Lagrange summary, status
-    if (g == 0) {
-      stv_n<NT, QPL>(vp, j, nn, xv);
-      if (j < k) vp[nn + m + j] = yv;
-    }
+    if (!residual_mode) {  // the state is an input only there
+      if (g == 0) {
+        stv_n<NT, QPL>(vp, j, nn, xv);
+        if (j < k) vp[nn + m + j] = yv;
+      }
 #pragma unroll
-    for (int ci = 0; ci < MC; ++ci)
-      if (lane + 64 * ci < m) { vp[nn + lane + 64 * ci] = cs[ci]; vp[nn + m + k + lane + 64 * ci] = cz[ci]; }
+      for (int ci = 0; ci < MC; ++ci)
+        if (lane + 64 * ci < m) { vp[nn + lane + 64 * ci] = cs[ci]; vp[nn + m + k + lane + 64 * ci] = cz[ci]; }
+    }
     const double ymin = row_min((j < k) ? yv : INFINITY), yabs = -row_min((j < k) ? -fabs(yv) : INFINITY);
     if (lane == 0) {
       if (a.termination) a.termination[p] = term;
@@ -1844,12 +1879,15 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 bool fused_supported(const KernelArgs& a, int dtype) {
-  if (dtype != MO_F64 || a.flags != 0) return false;
+  if (dtype != MO_F64) return false;
+  if (a.flags & ~MO_STEP_NO_INEQUALITIES) return false;
+  if (a.flags && a.mode != MODE_STEP && a.mode != MODE_RESIDUAL) return false;
   if (a.mode == MODE_LINEARIZE) {  // standalone J^T J: J-level fp64 only, same layout rules as the step kernel
     return a.J && a.ticket && a.G_out && a.c_out && a.n >= 2 && a.n <= 128 && !(a.n & 1) && a.J_row_major && a.J_ld == a.n && a.m_r > 0 &&
            aligned16(a.J) && !(a.J_stride & 1) && a.G_out_ld >= a.n;
   }
-  if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP) return false;
+  if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP && a.mode != MODE_RESIDUAL) return false;
+  if (a.mode == MODE_RESIDUAL && !a.r_out) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.k > 15 || a.m < 0) return false;
   // two constraint slots per lane (m <= 128): the step kernel on every tile grid, Solve / Iterate on the 32 / 64 grids
@@ -1868,7 +1906,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
 }
 
 const char* fused_name(const KernelArgs& a, int) {
-  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {
+  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {
     if (!a.J) return a.n > 96 ? "fused_solve_qp_f64_n128" : a.n > 64 ? "fused_solve_qp_f64_n96" : a.n > 32 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
     return a.n > 96 ? "fused_solve_mfma_f64_n128" : a.n > 64 ? "fused_solve_mfma_f64_n96" : a.n > 32 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
   }
@@ -1903,7 +1941,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     return hipGetLastError();
   }
   if (a.J && (a.n & 1)) {  // odd n: flat-group J stream
-    const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE;
+    const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
     const int wf = (a.n > 32 && solve) ? 2 : 3;
     long long fgrid = num_cus;
     const long long fneed = (a.batch + 4 * wf - 1) / (4 * wf);
@@ -1955,7 +1993,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     return hipGetLastError();
   }
   if (a.n > 64) {  // 96 / 128-variable tile grids: correctness-first instantiations (the 128 one spills), one or two waves per SIMD
-    const bool big = a.n > 96, solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE;
+    const bool big = a.n > 96, solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
     const int bw = (!big && !solve) ? 2 : 1;
     long long bgrid = num_cus;
     const long long bneed = (a.batch + 4 * bw - 1) / (4 * bw);
@@ -1971,7 +2009,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
     }
     return hipGetLastError();
   }
-  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
+  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
     const int swps = a.n > 32 ? 2 : 3;
     long long sgrid = num_cus;
     const long long need = (a.batch + 4 * swps - 1) / (4 * swps);

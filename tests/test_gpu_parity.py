@@ -744,6 +744,12 @@ def test_fused_vs_generic_random_shapes():
             s.SetVariables(T(vars_))
             delta, alpha, status = s.NewtonStep(T(mu), 0.995)
             assert torch.all(status == 0), tag
+            delta = delta.clone()
+            d0, a0, st0 = s.NewtonStep(T(mu), 0.995, include_inequalities=False)      # SolveForUpdateNoInequalities, qp.cc:366-386
+            assert torch.all(st0 == 0), tag
+            res_all = [t.cpu().numpy().copy() for t in s.EvaluateKKTConditions(T(mu))]              # qp.cc:391-437
+            res_eq = [t.cpu().numpy().copy() for t in s.EvaluateKKTConditions(T(mu), include_inequalities=False)]
+            extra = (d0.cpu().numpy().copy(), a0.cpu().numpy().copy(), res_all, res_eq)
             ip, st2 = s.Iterate(T(mu), strategy)
             assert torch.all(st2 == 0), tag
             after_iter = s.variables().cpu().numpy().copy()
@@ -751,9 +757,19 @@ def test_fused_vs_generic_random_shapes():
                                    initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
             assert torch.all(out.status == 0), tag
             got[force] = (delta.cpu().numpy(), alpha.cpu().numpy(), ip.cpu().numpy(), after_iter, s.variables().cpu().numpy().copy(),
-                          out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
+                          out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy(), extra)
         f, g_ = got[False], got[True]
         assert rel_inf_rows(f[0], g_[0]).max() < 1e-8, tag
+        # the step without inequalities (dx, dy only; ds = dz = 0; alpha = 1) and the KKT residual with its four norms, fused vs generic
+        (fd0, fa0, fr, fre), (gd0, ga0, gr, gre) = f[7], g_[7]
+        np.testing.assert_allclose(fd0, gd0, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(gd0).max()), err_msg=str(tag))
+        assert np.all(fd0[:, n:n + m] == 0) and np.all(fd0[:, n + m + k:] == 0) and np.all(fa0 == 1.0) and np.all(ga0 == 1.0), tag
+        scale = max(1.0, np.abs(gr[0]).max())
+        np.testing.assert_allclose(fr[0], gr[0], rtol=1e-10, atol=1e-12 * scale, err_msg=str(tag))
+        np.testing.assert_allclose(fr[1], gr[1], rtol=1e-9, atol=1e-12 * scale, err_msg=str(tag))
+        keep = np.r_[0:n, n + m:n + m + k]                                            # r_d and r_pe are what the flag leaves defined
+        np.testing.assert_allclose(fre[0][:, keep], gre[0][:, keep], rtol=1e-10, atol=1e-12 * scale, err_msg=str(tag))
+        np.testing.assert_allclose(fre[1][:, [0, 2]], gre[1][:, [0, 2]], rtol=1e-9, atol=1e-12 * scale, err_msg=str(tag))
         np.testing.assert_allclose(f[1], g_[1], atol=1e-8, err_msg=str(tag))
         np.testing.assert_allclose(f[2], g_[2], rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=str(tag))
         np.testing.assert_allclose(f[3], g_[3], rtol=1e-7, atol=1e-9, err_msg=str(tag))
@@ -829,11 +845,13 @@ def test_large_fp64_plan_falls_back_cleanly():
     s.SetVariables(T(vars_))
     delta, alpha, status = s.NewtonStep(0.1, 0.995)
     assert torch.all(status == 0) and torch.isfinite(delta).all()
+    d0, a0, st0 = s.NewtonStep(0.1, 0.995, include_inequalities=False)   # MO_STEP_NO_INEQUALITIES and the KKT residual run fused as well
+    assert torch.all(st0 == 0) and torch.isfinite(d0).all() and torch.all(a0 == 1.0)
+    r_, kkt = s.EvaluateKKTConditions(0.1)
+    assert torch.isfinite(r_).all() and torch.isfinite(kkt).all()
     with pytest.raises(L.MiniOptError) as e:
-        s.NewtonStep(0.1, 0.995, include_inequalities=False)       # MO_STEP_NO_INEQUALITIES lives on the generic kernel only
-    assert "LDS" in str(e.value)
-    with pytest.raises(L.MiniOptError):
         Q.QPInteriorPointSolver(prob, force_generic=True).NewtonStep(0.1, 0.995)
+    assert "LDS" in str(e.value)
     G, c, half = Q.linearize(prob)                                   # n = 128 alone still fits the generic kernel (k = m = 0 there)
     np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
 
