@@ -505,9 +505,15 @@ template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int 
 // FLAT (odd n: rows of J are not 16-byte aligned, a 16-byte piece would straddle two rows): the 4-row group is copied as ONE flat
 // run of 32 nn bytes by dword DMAs (N / 8 instructions, the ones beyond the run parked on a trash word so that the hand-counted
 // vmcnt stays exact) and each lane picks its operands out of the slot with 8-byte LDS reads, masking the columns >= nn.
-template <int NT, int D, bool FLAT = false>
+// GATHER (JMODE 2: any other layout of J -- column-major, a leading dimension beyond n, rows that are only 8-byte aligned): every lane
+// fetches its own operands J(4s+g, col) as two dwords each through per-lane LDS-DMA addresses (wave-uniform part of the address on the
+// scalar unit: base + column part; one VGPR holds the lane part g * row_stride + 2j * column_stride).  2 NT + 1 DMAs per group, operand c
+// at dwords [2c][lane] and [2c+1][lane] of the slot.  The memory system sees 4-byte pieces: this is the flexible path, not the fast one.
+constexpr int JMODE_VECTOR = 0, JMODE_FLAT = 1, JMODE_GATHER = 2;
+template <int NT, int D, int JMODE = JMODE_VECTOR>
 struct JStream {
-  static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, NI = FLAT ? N / 8 : NH, DPS = NI + 1, SLOT = NH * 1024 + 64;
+  static constexpr bool FLAT = JMODE == JMODE_FLAT, GATHER = JMODE == JMODE_GATHER;
+  static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, NI = GATHER ? 2 * NT : (FLAT ? N / 8 : NH), DPS = NI + 1, SLOT = NH * 1024 + 64;
   static_assert((D - 1) * DPS <= 63, "vmcnt is a 6-bit counter");
   static_assert(D >= 2 && D <= 8, "ring depth");
   const char* jbase;   // wave-uniform: row 4s of J
@@ -520,23 +526,53 @@ struct JStream {
   const char* r_elem;
   unsigned ring_base;
   int lane, nsteps;
+  long long rs_, cs_;  // GATHER: row / column stride of J in bytes (wave-uniform)
 
+  // rs / cs: element strides between rows / columns of J (row-major packed: nn, 1).  Only the GATHER stream looks at them.
   __device__ inline void init(const double* Jp, const double* rg, const char* smem, unsigned ring_base_, int lane_, int g, int j, int m_r,
-                              int nn = N) {
+                              int nn = N, long long rs = -1, long long cs = 1) {
+    if (rs < 0) rs = nn;
     jbase = reinterpret_cast<const char*>(Jp);
     rbase = reinterpret_cast<const char*>(rg);
-    joff = (unsigned)(g * nn + 2 * j) * 8u;
-    jstep = 32u * (unsigned)nn;
+    rs_ = 8 * rs; cs_ = 8 * cs;
+    joff = GATHER ? (unsigned)(g * rs_ + 2 * j * cs_) : (unsigned)(g * nn + 2 * j) * 8u;
+    jstep = GATHER ? (unsigned)(4 * rs_) : 32u * (unsigned)nn;
     act0 = 2 * j < nn; act1 = 32 + 2 * j < nn; act2 = 64 + 2 * j < nn; act3 = 96 + 2 * j < nn;
     roff = 4u * (unsigned)lane_;                             // lanes 0..7 fetch the eight dwords of r[4s .. 4s+3] (no 16-byte alignment)
     lane_piece = smem + lane_ * 16;                          // this lane's 16 bytes inside a 1 KiB DMA piece
     r_elem = smem + NH * 1024 + 8 * g;                       // r[4s + g] inside a slot
     ring_base = ring_base_; lane = lane_; nsteps = m_r >> 2;
     rem = m_r & 3; row_len = nn; g_ = g; j_ = j;
-    tail_j = Jp + (size_t)(4 * nsteps) * nn; tail_r = rg + 4 * nsteps;
+    tail_j = Jp + (size_t)(4 * nsteps) * (GATHER ? rs : (long long)nn); tail_r = rg + 4 * nsteps;
+  }
+  template <int IMM> __device__ static inline void dma4_si(const void* sbase_in, unsigned voff, unsigned lds_dst_in) {  // dma4_s + instruction offset
+    const void* sbase = uniform_ptr(sbase_in);
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM)
+        : "memory");
   }
   template <int SL> __device__ inline void issue() {  // DMAs of the next not-yet-issued 4-row group into ring slot SL
     const unsigned dst = ring_base + SL * SLOT;
+    if (GATHER) {
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const int col0 = 32 * (c >> 1) + (c & 1);                 // column of lane j = 0 (wave-uniform)
+        if (col0 < row_len) {                                     // lane 0 is inside: lanes beyond the row sit the DMA out, the ring holds zeros there
+          const char* sb = jbase + (long long)col0 * cs_;
+          if (col0 + 2 * j_ < row_len) { dma4_si<0>(sb, joff, dst + 512 * c); dma4_si<4>(sb, joff, dst + 512 * c + 256 - 4); }
+        } else {                                                  // operand wholly outside the row: keep the DMA count constant
+          if (lane == 0) { dma4_si<0>(jbase, 0u, dst + NH * 1024 + 48); dma4_si<0>(jbase, 0u, dst + NH * 1024 + 48); }
+        }
+      }
+      if (lane < 8) dma4_s(rbase, roff, dst + NH * 1024);
+      jbase += jstep;
+      rbase += 32;
+      return;
+    }
     if (FLAT) {
       const int run = 32 * row_len;  // bytes of the group
 #pragma unroll
@@ -576,7 +612,11 @@ struct JStream {
   template <int SL, bool RSQ = false> __device__ inline void consume(int q, d4 (&U)[NB * NB], double (&cpart)[NT]) {  // group q sits in slot SL
     wait_for_oldest(nsteps - 1 - q);
     double ops[NT];
-    if (FLAT) {
+    if (GATHER) {
+      const int* src = reinterpret_cast<const int*>(lane_piece - lane * 16 + SL * SLOT) + lane;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) ops[c] = __hiloint2double(src[128 * c + 64], src[128 * c]);
+    } else if (FLAT) {
       const double* src = reinterpret_cast<const double*>(lane_piece - lane * 16 + SL * SLOT) + g_ * row_len + 2 * j_;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -623,11 +663,20 @@ struct JStream {
       for (int c = 0; c < NT; ++c) ops[c] = 0.0;
       double rq = 0.0;
       if (g_ < rem) {
-        const double* row = tail_j + (size_t)g_ * row_len + 2 * j_;
+        if (GATHER) {
+          const char* row = reinterpret_cast<const char*>(tail_j) + g_ * rs_ + 2 * j_ * cs_;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          if (32 * h + 2 * j_ < row_len) ops[2 * h] = row[32 * h];
-          if (32 * h + 2 * j_ + 1 < row_len) ops[2 * h + 1] = row[32 * h + 1];
+          for (int c = 0; c < NT; ++c) {
+            const int col0 = 32 * (c >> 1) + (c & 1);
+            if (col0 + 2 * j_ < row_len) ops[c] = *reinterpret_cast<const double*>(row + (long long)col0 * cs_);
+          }
+        } else {
+          const double* row = tail_j + (size_t)g_ * row_len + 2 * j_;
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            if (32 * h + 2 * j_ < row_len) ops[2 * h] = row[32 * h];
+            if (32 * h + 2 * j_ + 1 < row_len) ops[2 * h + 1] = row[32 * h + 1];
+          }
         }
         rq = tail_r[g_];
       }
@@ -878,7 +927,7 @@ template <int NT, int WPS, int MC = 1> struct FusedCfg {
 
 // One workgroup of 4*WPS independent waves per CU (so that exactly WPS waves sit on every SIMD).  The waves never
 // synchronise with each other; each owns its slice of the workgroup's LDS.
-template <int NT, int WPS, int SW, bool QPL, int MC = 1, bool FLAT = false>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
   using C = FusedCfg<NT, WPS, MC>;
   constexpr int MCAP = C::MCAP;
@@ -965,9 +1014,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const double* vp = (const double*)ka->vars + p * ka->vars_stride;
 
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
-    JStream<NT, D, FLAT> stream;
+    JStream<NT, D, JMODE> stream;
     if (!QPL) {
-      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
+      stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
       stream.prologue();
     }
 
@@ -1305,7 +1354,7 @@ template <int NT, int WPS, int MC = 1> struct SolveCfg {
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
 
-template <int NT, int WPS, int SW, bool QPL, int MC = 1, bool FLAT = false>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
   using C = SolveCfg<NT, WPS, MC>;
   constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
@@ -1489,10 +1538,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // kept in VGPRs across the factorisation (see the step kernel)
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
       // ---------------------------------------------------------------- part A: tiles, residual, norms
-      JStream<NT, D, FLAT> stream;
+      JStream<NT, D, JMODE> stream;
       const bool stream_now = !QPL && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;  // wave-uniform, and hipcc must know it
       if (stream_now) {
-        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn);
+        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
         stream.prologue();
       }
       d4 U[NB * NB];
@@ -1878,6 +1927,16 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+#ifndef MO_FUSED_IMPL_ONLY  // kkt_fused_gather.hip includes this file for the templates only
+// J-level input whose layout the 16-byte / flat streams cannot take: column-major, a leading dimension beyond n, rows that are not 16-byte
+// aligned (even n), odd n beyond the flat stream's 64 -- served by the per-lane gather stream (JMODE_GATHER, kkt_fused_gather.hip).
+bool fused_needs_gather(const KernelArgs& a) {
+  if (!a.J) return false;
+  if (!a.J_row_major || a.J_ld != a.n) return true;
+  if (a.n & 1) return a.n > 64 || a.m > 64;
+  return !aligned16(a.J) || (a.J_stride & 1);
+}
+
 bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64) return false;
   if (a.flags & ~MO_STEP_NO_INEQUALITIES) return false;
@@ -1894,11 +1953,10 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.m > ((a.mode == MODE_STEP || a.n <= 64) ? 128 : 64)) return false;
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
-  if (a.J) {  // J-level: 16-byte pieces of J and r (the state / direction vectors are accessed 8 bytes at a time)
-    if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0) return false;  // m_r % 4 rows are handled after the ring stream
-    // odd n: rows of J are only 8-byte aligned -> the flat-group stream (32 / 64 grids, one constraint slot per lane)
-    if ((a.n & 1) && (a.n > 64 || a.m > 64)) return false;
-    if (!(a.n & 1) && (!aligned16(a.J) || (a.J_stride & 1))) return false;  // the 16-byte pieces of the even-n stream
+  if (a.J) {  // J-level: 16-byte pieces of a packed row-major J (even n), the flat-group stream (odd n <= 64), or the gather stream
+    if (a.m_r <= 0) return false;  // m_r % 4 rows are handled after the ring stream
+    if (a.J_ld < (a.J_row_major ? a.n : a.m_r)) return false;
+    if (fused_needs_gather(a) && a.m > 64) return false;  // the gather instantiations carry one constraint slot per lane
   } else {    // QP-level: G, c given; no alignment requirements
     if (!a.G || !a.c || a.G_ld < a.n) return false;
   }
@@ -1927,6 +1985,9 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
+#ifndef MO_FUSED_STAMPS  // (the diagnostic build of tools/phase_timer.hip links this file alone)
+  if (a.mode != MODE_LINEARIZE && fused_needs_gather(a)) return launch_fused_gather(a, num_cus, stream);
+#endif
   if (a.mode == MODE_LINEARIZE) {
     const int wl = a.n > 96 ? 1 : (a.n > 64 ? 2 : 3);
     long long lgrid = num_cus;
@@ -2061,5 +2122,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
 #undef MO_FUSED_LAUNCH
   return hipGetLastError();
 }
+
+#endif  // MO_FUSED_IMPL_ONLY
 
 }  // namespace mo

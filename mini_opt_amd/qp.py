@@ -42,6 +42,8 @@ class BatchedQP:
 
     Tensor layouts (contiguous, problem index first):
       J    [B, m_r, n]  stacked Jacobian rows (row-major)         r  [B, m_r]      lam: LM damping (nonlinear.cc:187-189)
+           other layouts the C ABI takes: J_layout = "row" with J [B, m_r, ld >= n] (a leading dimension beyond n), or
+           J_layout = "col" with J [B, n, ld >= m_r] (column-major: tensor row i is column i of J; J_rows = m_r if ld > m_r)
       G    [B, n, n]    memory = n x n COLUMN-major, lower triangle read (pass G_colmajor[b] = G.T for a symmetric G)
       c    [B, n]
       A_eq [B, n, k]    memory = k x n COLUMN-major (A_eq[b] = A.T)  b_eq [B, k]
@@ -62,10 +64,16 @@ class BatchedQP:
     cons_var: Optional[torch.Tensor] = None
     cons_a: Optional[torch.Tensor] = None
     cons_b: Optional[torch.Tensor] = None
+    J_layout: str = "row"
+    J_rows: Optional[int] = None
 
     @property
     def m_r(self) -> int:
-        return 0 if self.J is None else int(self.J.shape[1])
+        if self.J is None:
+            return 0
+        if self.J_layout == "col":
+            return int(self.J_rows if self.J_rows is not None else self.J.shape[2])
+        return int(self.J.shape[1])
 
     @property
     def V(self) -> int:
@@ -109,8 +117,18 @@ class BatchedQP:
 
         n, k, m = self.n, self.k, self.m
         if self.J is not None:
-            chk(self.J, (self.m_r, n)); chk(self.r, (self.m_r,))
-            p.J, p.J_stride, p.J_ld, p.J_layout = _ptr(self.J), stride(self.J, self.m_r * n), n, L.MO_ROW_MAJOR
+            chk(self.r, (self.m_r,))
+            ld = int(self.J.shape[2])
+            if self.J_layout == "col":
+                chk(self.J, (n, ld))
+                if ld < self.m_r:
+                    raise ValueError("column-major J: leading dimension < m_r")
+                p.J, p.J_stride, p.J_ld, p.J_layout = _ptr(self.J), stride(self.J, n * ld), ld, L.MO_COL_MAJOR
+            else:
+                chk(self.J, (self.m_r, ld))
+                if ld < n:
+                    raise ValueError("row-major J: leading dimension < n")
+                p.J, p.J_stride, p.J_ld, p.J_layout = _ptr(self.J), stride(self.J, self.m_r * ld), ld, L.MO_ROW_MAJOR
             p.r, p.r_stride = _ptr(self.r), stride(self.r, self.m_r)
             p.lam = float(self.lam)
             if self.lam_vec is not None:

@@ -1044,3 +1044,63 @@ def test_fused_odd_n_with_stacked_jacobian(n, k, m, m_r):
     same = (res[False][2] == res[True][2]) & (res[False][3] == res[True][3]) & (res[False][3] == Q.SATISFIED_KKT_TOL)
     assert same.mean() >= 0.7, (res[False][2], res[True][2], res[False][3])
     np.testing.assert_allclose(res[False][1][same][:, :n], res[True][1][same][:, :n], rtol=1e-6, atol=1e-8)
+
+
+# ------------------------------------------------------------------ J in the other layouts of the C ABI: the per-lane gather stream
+def _layouts_of(J):
+    """The same stacked Jacobian [B, m_r, n] as (label, tensor, BatchedQP keyword arguments) in every layout mo_problem accepts."""
+    B, m_r, n = J.shape
+    out = [("packed", T(J), {})]
+    wide = np.full((B, m_r, n + 5), 7.7); wide[:, :, :n] = J                       # row-major, leading dimension n + 5
+    out.append(("row ld=n+5", T(wide), {}))
+    colm = np.ascontiguousarray(J.transpose(0, 2, 1))                               # column-major, ld = m_r
+    out.append(("col", T(colm), dict(J_layout="col")))
+    colw = np.full((B, n, m_r + 3), -3.3); colw[:, :, :m_r] = J.transpose(0, 2, 1)   # column-major, ld = m_r + 3
+    out.append(("col ld=m_r+3", T(colw), dict(J_layout="col", J_rows=m_r)))
+    flat = torch.zeros(B * m_r * n + 1, dtype=torch.float64, device="cuda:0")       # packed but starting 8 bytes off a 16-byte boundary
+    flat[1:] = T(J).reshape(-1)
+    out.append(("unaligned", flat[1:].view(B, m_r, n), {}))
+    return out
+
+
+@pytest.mark.parametrize("n,k,m,m_r", [(64, 8, 32, 128), (32, 4, 16, 64), (40, 3, 10, 50), (63, 8, 32, 131), (96, 8, 40, 192), (101, 5, 20, 203),
+                                       (128, 10, 40, 256), (6, 2, 4, 9)])
+def test_fused_kernels_take_every_layout_of_J(n, k, m, m_r):
+    """Column-major J, a leading dimension beyond n, rows that are only 8-byte aligned, odd n beyond 64: all of them run on the fused
+    kernels (the gather stream, kkt_fused_gather.hip) and give the packed layout's results -- step against the oracle, Iterate, Solve and
+    the KKT residual against the packed run."""
+    rng = np.random.default_rng(n * 7 + m_r)
+    B = 7
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n)); sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1); mu = np.full(B, 0.05)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, J=J, r=r, lam=1e-3, A_eq=A, b_eq=b, cons_var=cv, cons_a=ca, cons_b=cb,
+                                                            vars_=vars_, mu=mu)
+    assert np.all(ref_status == 0)
+    base = None
+    for label, Jt, kw in _layouts_of(J):
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=Jt, r=T(r), lam=1e-3, A_eq=T(A), b_eq=T(b), cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb), **kw)
+        s = Q.QPInteriorPointSolver(prob)
+        assert s.step_kernel().startswith("fused"), (label, s.step_kernel())
+        s.SetVariables(T(vars_))
+        delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+        assert torch.all(status == 0), label
+        assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-10, label
+        np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9, err_msg=label)
+        res = [t.cpu().numpy().copy() for t in s.EvaluateKKTConditions(T(mu))]
+        ip, st2 = s.Iterate(T(mu), Q.PREDICTOR_CORRECTOR)
+        assert torch.all(st2 == 0), label
+        after = s.variables().cpu().numpy().copy()
+        out = s.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED))
+        assert torch.all(out.status == 0), label
+        got = (delta.cpu().numpy().copy(), res, ip.cpu().numpy().copy(), after, s.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy().copy(),
+               out.termination_state.cpu().numpy().copy())
+        if base is None:
+            base = got
+            continue
+        # the gather stream feeds the matrix cores the same operands in the same order: identical arithmetic
+        for a_, b_ in zip((got[0], got[1][0], got[1][1], got[2], got[3], got[4]), (base[0], base[1][0], base[1][1], base[2], base[3], base[4])):
+            np.testing.assert_allclose(a_, b_, rtol=1e-12, atol=1e-13, equal_nan=True, err_msg=label)
+        assert np.array_equal(got[5], base[5]) and np.array_equal(got[6], base[6]), label

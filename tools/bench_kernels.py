@@ -25,12 +25,21 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-records", action="store_true", help="Solve without the per-iteration records")
+    ap.add_argument("--layout", default="packed", choices=["packed", "col", "rowld"],
+                    help="layout of J: packed row-major (16-byte stream), column-major or row-major with ld = n + 2 (gather stream)")
     args = ap.parse_args()
     d = synth.CONFIGS[args.config]
     dev = torch.device("cuda:0")
     dt = torch.float64 if d["dtype"] == "f64" else torch.float32
     batch = args.batch or d["batch"]
     prob, vars_, mu = synth.make_batch_torch(d["n"], d["k"], d["m"], d["m_r"], batch, dev, dt)
+    if args.layout == "col":
+        prob.J = prob.J.transpose(1, 2).contiguous()
+        prob.J_layout = "col"
+    elif args.layout == "rowld":
+        wide = torch.zeros(batch, d["m_r"], d["n"] + 2, dtype=dt, device=dev)
+        wide[:, :, :d["n"]] = prob.J
+        prob.J = wide
     extra = {}
     if args.mode in ("step", "generic"):
         s = Q.QPInteriorPointSolver(prob, force_generic=args.mode == "generic")
@@ -75,7 +84,7 @@ def main():
         extra = {"mean_iterations": float(o.num_iterations.double().mean()), "satisfied_frac": float((o.termination_state == 0).double().mean()),
                  "status_ok_frac": float((o.status == 0).double().mean())}
     T = 8 if d["dtype"] == "f64" else 4
-    print(json.dumps({"mode": args.mode, "config": args.config, "batch": batch, "kernel": kernel, "reps": args.reps,
+    print(json.dumps({"mode": args.mode, "config": args.config, "layout": args.layout, "batch": batch, "kernel": kernel, "reps": args.reps,
                       "ms_mean": sum(ms) / len(ms), "ms_min": ms[0], "units_per_s": batch / (sum(ms) / len(ms) * 1e-3),
                       "algorithmic_bytes_per_unit_step": synth.algorithmic_bytes(d["n"], d["k"], d["m"], d["m_r"], T), **extra}), flush=True)
 
