@@ -1985,7 +1985,7 @@ hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t strea
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-#ifndef MO_FUSED_STAMPS  // (the diagnostic build of tools/phase_timer.hip links this file alone)
+#if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)  // (the diagnostic builds of tools/phase_timer*.hip link this file alone)
   if (a.mode != MODE_LINEARIZE && fused_needs_gather(a)) return launch_fused_gather(a, num_cus, stream);
 #endif
   if (a.mode == MODE_LINEARIZE) {

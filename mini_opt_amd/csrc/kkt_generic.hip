@@ -42,6 +42,21 @@
 namespace mo {
 namespace {
 
+#ifdef MO_GENERIC_STAMPS
+__device__ unsigned long long g_nd_stamps[8];   // diagnostic build only: where newton_direction spends its time
+#define MO_NDSTAMP(i)                                                              \
+  do {                                                                             \
+    __syncthreads();                                                               \
+    if (threadIdx.x == 0) {                                                        \
+      const unsigned long long t__ = __builtin_amdgcn_s_memtime();                 \
+      atomicAdd(&g_nd_stamps[i], t__ - nd_prev);                                   \
+      nd_prev = t__;                                                               \
+    }                                                                              \
+  } while (0)
+#else
+#define MO_NDSTAMP(i) do { } while (0)
+#endif
+
 // Workgroup size is chosen at launch: 256 threads (4 waves) for large systems, ONE wave for small ones (n + k <= 48), where a
 // 256-thread workgroup would idle on P-long loops and up to 32 single-wave workgroups fit a CU instead of 8.
 constexpr int kMaxThreads = 256;
@@ -144,12 +159,41 @@ __device__ void load_qp(const Ws<T>& w, int n, int k, const T* G, int G_ld, cons
   __syncthreads();
 }
 
+template <typename T, int TG, int RN>
+__device__ inline void jtj_tile_rows_impl(const Ws<T>& w, int n, int rows, int tid) {
+  const int ti = tid & (TG - 1), tj = tid / TG;
+  T acc[RN * (RN + 1) / 2];
+#pragma unroll
+  for (int e = 0; e < RN * (RN + 1) / 2; ++e) acc[e] = (T)0;
+  int ic[RN], jc[RN];
+#pragma unroll
+  for (int b = 0; b < RN; ++b) {   // clamped column indices: out-of-range operands are read (in bounds) and their results never stored
+    ic[b] = ti + TG * b < n ? ti + TG * b : n - 1;
+    jc[b] = tj + TG * b < n ? tj + TG * b : n - 1;
+  }
+  for (int q = 0; q < rows; ++q) {
+    const T* row = w.Jc + (size_t)q * n;
+    T a[RN], b[RN];
+#pragma unroll
+    for (int e = 0; e < RN; ++e) { a[e] = row[ic[e]]; b[e] = row[jc[e]]; }
+#pragma unroll
+    for (int bi = 0; bi < RN; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) acc[bi * (bi + 1) / 2 + bj] += a[bi] * b[bj];
+  }
+#pragma unroll
+  for (int bi = 0; bi < RN; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = ti + TG * bi, j = tj + TG * bj;
+      if (i < n && j <= i) w.H[i + (size_t)j * w.ldh] += acc[bi * (bi + 1) / 2 + bj];
+    }
+}
 // H.lower(n x n) += J^T J, cvec = J^T r, diag += lambda; returns 0.5|r|^2 in w.red[8]   (residual.hpp:206-225,
 // nonlinear.cc:182-189).  H must be zero in its n x n block and cvec is overwritten.
-template <typename T>
+template <typename T, int TG, int R>
 __device__ void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r,
                                T lambda, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < n; i += kThreads) w.cvec[i] = (T)0;
   if (tid == 0) w.red[8] = (T)0;
   __syncthreads();
@@ -169,27 +213,9 @@ __device__ void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J
     }
     for (int idx = tid; idx < rows; idx += kThreads) w.rc[idx] = r[q0 + idx];
     __syncthreads();
-    // each wave owns groups of 4 columns; lanes own rows i >= j0
-    for (int j0 = wave * 4; j0 < n; j0 += 4 * kWaves) {
-      const int jc0 = j0, jc1 = (j0 + 1 < n) ? j0 + 1 : n - 1, jc2 = (j0 + 2 < n) ? j0 + 2 : n - 1,
-                jc3 = (j0 + 3 < n) ? j0 + 3 : n - 1;
-      for (int i0 = j0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const int ic = i < n ? i : n - 1;
-        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int q = 0; q < rows; ++q) {
-          const T* row = w.Jc + (size_t)q * n;
-          const T ji = row[ic];
-          a0 += ji * row[jc0]; a1 += ji * row[jc1]; a2 += ji * row[jc2]; a3 += ji * row[jc3];
-        }
-        if (i < n) {
-          if (i >= j0) w.H[i + (size_t)j0 * w.ldh] += a0;
-          if (j0 + 1 < n && i >= j0 + 1) w.H[i + (size_t)(j0 + 1) * w.ldh] += a1;
-          if (j0 + 2 < n && i >= j0 + 2) w.H[i + (size_t)(j0 + 2) * w.ldh] += a2;
-          if (j0 + 3 < n && i >= j0 + 3) w.H[i + (size_t)(j0 + 3) * w.ldh] += a3;
-        }
-      }
-    }
+    // 2-D register tiling: thread (ti, tj) of a TG x TG grid accumulates G(i, j) for i = ti + TG bi, j = tj + TG bj, bi >= bj: per row of
+    // J it reads RN + RN operands (broadcasts) for RN (RN + 1) / 2 FMAs, instead of five LDS reads for four FMAs
+    jtj_tile_rows_impl<T, TG, R>(w, n, rows, tid);   // n <= n + k <= TG R
     for (int i = tid; i < n; i += kThreads) {
       T acc = 0;
       for (int q = 0; q < rows; ++q) acc += w.Jc[(size_t)q * n + i] * w.rc[q];
@@ -281,11 +307,92 @@ __device__ void compute_mu(const Ws<T>& w, int n, int k, int m, int tid) {
   __syncthreads();
 }
 
+// Right-looking LDL^T (natural order, Eigen's zero-pivot rules: a zero pivot is tolerated iff the column below it is exactly zero, a
+// non-zero pivot after a zero one is a failure) with the lower triangle of H held in the REGISTERS of the workgroup: a TG x TG thread
+// grid, element (i, j) with thread (i mod TG, j mod TG) at local block (i / TG, j / TG) -- R (R + 1) / 2 values per thread, R = ceil(P /
+// TG).  Per pivot the 16 (8) threads that own column k publish it to LDS (entries at and above the diagonal as zeros), one barrier, and
+// every thread applies the rank-1 update to ALL its registers with 2 R broadcast reads: rows / columns that are already finished meet
+// the zeros and stay.  The LDS-resident loop this replaces read two operands and wrote one result through LDS for every FMA.
+// Afterwards H holds W = L D below the diagonal and invd = 1 / D, as the triangular solves expect.
+template <typename T, int TG, int R>
+__device__ int factor_in_registers(const Ws<T>& w, int P, int tid) {
+  const int ti = tid & (TG - 1), tj = tid / TG;
+  T h[R * (R + 1) / 2];
+#pragma unroll
+  for (int bi = 0; bi < R; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = ti + TG * bi, j = tj + TG * bj;
+      h[bi * (bi + 1) / 2 + bj] = (i < P && j <= i) ? w.H[i + (size_t)j * w.ldh] : (T)0;
+    }
+  // two column buffers (alternating: one barrier per pivot): rhs (P) and delta (V >= P) are both rewritten by the solve that follows
+  T* const colbuf[2] = {w.rhs, w.delta};
+  bool found_zero = false;
+  int status = MO_STATUS_OK;
+  for (int kk = 0; kk < P; ++kk) {
+    T* const col = colbuf[kk & 1];
+    const int bk = kk / TG, rk = kk - bk * TG;
+    if (tj == rk) {  // the owners of column kk publish it: col[i] = H(i, kk) for i > kk, 0 above, the pivot itself at col[kk]
+#pragma unroll
+      for (int bi = 0; bi < R; ++bi) {
+        const int i = ti + TG * bi;
+        if (i < P) {
+          T v = (T)0;
+#pragma unroll
+          for (int bj = 0; bj <= bi; ++bj)
+            if (bj == bk) v = h[bi * (bi + 1) / 2 + bj];   // compile-time register index, runtime select
+          col[i] = i >= kk ? v : (T)0;
+          if (i == kk) {  // the owner of the pivot also publishes 1 / d: one reciprocal per pivot instead of one per thread
+            T q = (T)1 / v;   // (a zero pivot gives inf here; the branch below never uses it)
+            w.invd[kk] = q;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const T d = col[kk];
+    const bool valid = absT(d) > (T)0;
+    if (!valid) {  // uniform: zero (or NaN) pivot
+      bool nz = false;
+      for (int i = kk + 1 + tid; i < P; i += kThreads) nz |= !(col[i] == (T)0);
+      if (nz || !(d == (T)0)) w.iflag[1] = 1;
+      __syncthreads();
+      if (tid == 0) w.invd[kk] = (T)0;
+      if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }
+      found_zero = true;
+      continue;
+    }
+    if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; break; }  // non-zero pivot after a zero pivot
+    const T inv = w.invd[kk];
+    T ci[R], wj[R];
+#pragma unroll
+    for (int b = 0; b < R; ++b) {
+      const int i = ti + TG * b, j = tj + TG * b;
+      ci[b] = (i < P && i > kk) ? col[i] : (T)0;
+      wj[b] = (j < P && j > kk) ? col[j] * inv : (T)0;
+    }
+#pragma unroll
+    for (int bi = 0; bi < R; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) h[bi * (bi + 1) / 2 + bj] -= ci[bi] * wj[bj];
+  }
+  __syncthreads();
+  if (status != MO_STATUS_OK) return status;
+#pragma unroll
+  for (int bi = 0; bi < R; ++bi)
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      const int i = ti + TG * bi, j = tj + TG * bj;
+      if (i < P && j <= i) w.H[i + (size_t)j * w.ldh] = h[bi * (bi + 1) / 2 + bj];
+    }
+  __syncthreads();
+  return MO_STATUS_OK;
+}
+
 // Reduced-KKT assembly (Sigma on the diagonal, qp.cc:293-298) + LDL^T.  Returns MO_STATUS_*.
-template <typename T>
+template <typename T, int TG, int R>
 __device__ int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
   const int P = n + k;
-  const int lane = tid & 63, wave = tid >> 6;
   if (include_ineq) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
     for (int c = tid; c < m; c += kThreads)
@@ -300,32 +407,8 @@ __device__ int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool inc
     }
     __syncthreads();
   }
-  bool found_zero = false;
-  for (int kk = 0; kk < P; ++kk) {
-    const T* colk = w.H + (size_t)kk * w.ldh;
-    const T d = colk[kk];
-    const bool valid = absT(d) > (T)0;
-    if (!valid) {  // zero (or NaN) pivot: tolerated iff the column below is exactly zero (Eigen LDLT semantics)
-      bool nz = false;
-      for (int i = kk + 1 + tid; i < P; i += kThreads) nz |= !(colk[i] == (T)0);
-      if (nz || !(d == (T)0)) w.iflag[1] = 1;
-      if (tid == 0) w.invd[kk] = (T)0;
-      __syncthreads();
-      if (w.iflag[1]) return MO_STATUS_FACTORIZATION_FAILED;
-      found_zero = true;
-      continue;
-    }
-    if (found_zero) return MO_STATUS_FACTORIZATION_FAILED;  // non-zero pivot after a zero pivot
-    const T inv = (T)1 / d;
-    if (tid == 0) w.invd[kk] = inv;
-    for (int j = kk + 1 + wave; j < P; j += kWaves) {
-      const T wj = colk[j] * inv;
-      T* colj = w.H + (size_t)j * w.ldh;
-      for (int i = j + lane; i < P; i += 64) colj[i] -= colk[i] * wj;
-    }
-    __syncthreads();
-  }
-  return MO_STATUS_OK;
+  // ---- LDL^T with the matrix distributed over the workgroup's REGISTERS (the kernel is instantiated per thread grid TG and block count R)
+  return factor_in_registers<T, TG, R>(w, P, tid);
 }
 
 // Solve (L D L^T) sol = rhs in place, wave 0 only; H holds W = L D below the diagonal, invd = 1/D.
@@ -432,17 +515,22 @@ __device__ void compute_mu_affine(const Ws<T>& w, int n, int k, int m, T mu, T a
 
 // Iterate's solve part (qp.cc:163-193), state update excluded.  Residual must be current, H = G + A.
 // ip[6] receives IPIterationOutputs.  Returns MO_STATUS_*.
-template <typename T>
+template <typename T, int TG, int R>
 __device__ int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input, int strategy, T tau, T* ip, int tid) {
   const int V = n + 2 * m + k;
   ip[0] = mu_input; ip[1] = 1; ip[2] = 1; ip[3] = nanT<T>(); ip[4] = nanT<T>(); ip[5] = nanT<T>();
   for (int i = tid; i < V; i += kThreads) w.daff[i] = (T)0;                        // delta_affine_.setZero(), :315
-  const int st = assemble_and_factor(w, n, k, m, true, tid);
+#ifdef MO_GENERIC_STAMPS
+  unsigned long long nd_prev = __builtin_amdgcn_s_memtime();
+#endif
+  const int st = assemble_and_factor<T, TG, R>(w, n, k, m, true, tid);
+  MO_NDSTAMP(0);
   if (st != MO_STATUS_OK) return st;
   if (m == 0) {
     solve_for_update(w, n, k, m, (T)0, true, tid);                                // :165-167
   } else if (strategy != MO_PREDICTOR_CORRECTOR) {
     solve_for_update(w, n, k, m, mu_input, true, tid);                            // :169
+    MO_NDSTAMP(1);
   } else {
     solve_for_update(w, n, k, m, (T)0, true, tid);                                // :173
     compute_alpha(w, n, k, m, (T)1, tid);                                         // :174
@@ -475,8 +563,10 @@ __device__ void update_state(const Ws<T>& w, int n, int k, int m, T ap, T ad, in
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
-template <typename T, int MODE>
-__global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelArgs a) {
+// TG x TG = the thread grid of the register-distributed factorisation (8 x 8: single-wave workgroups, 16 x 16: 256 threads),
+// R = ceil((n + k) / TG) blocks per thread and dimension (also the block count of the J^T J register tiling: n <= TG R).
+template <typename T, int MODE, int TG, int R>
+__global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ws<T> w;
   const int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
@@ -525,7 +615,7 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
     MO_GSTAMP(1);
     if (j_level) {
       const T lam = a.lambda_vec ? ((const T*)a.lambda_vec)[p * a.lambda_vec_stride] : (T)a.lambda;  // per-problem LM state
-      accumulate_jtj(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, lam, tid);
+      accumulate_jtj<T, TG, R>(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, lam, tid);
       MO_GSTAMP(2);
       if (MODE == MODE_LINEARIZE || MODE == MODE_SOLVE) {
         // LINEARIZE output, or the per-problem G scratch the Solve loop reloads after each factorisation
@@ -563,12 +653,12 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
         eval_kkt(w, n, k, m, !no_ineq, tid);
         MO_GSTAMP(3);
         if (no_ineq) {
-          st = assemble_and_factor(w, n, k, m, false, tid);
+          st = assemble_and_factor<T, TG, R>(w, n, k, m, false, tid);
           if (st == MO_STATUS_OK) solve_for_update(w, n, k, m, (T)0, false, tid);
           ip[0] = mu_p; ip[1] = 1; ip[2] = 1; ip[3] = ip[4] = ip[5] = nanT<T>();
         } else {
           const int strat = (MODE == MODE_ITERATE) ? a.barrier_strategy : MO_COMPLEMENTARITY;
-          st = newton_direction(w, n, k, m, mu_p, strat, (T)a.tau, ip, tid);
+          st = newton_direction<T, TG, R>(w, n, k, m, mu_p, strat, (T)a.tau, ip, tid);
         }
       }
       MO_GSTAMP(4);
@@ -617,7 +707,7 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
         __syncthreads();
         if (sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED) {     // :455-460
           eval_kkt(w, n, k, m, false, tid);
-          st = assemble_and_factor(w, n, k, m, false, tid);
+          st = assemble_and_factor<T, TG, R>(w, n, k, m, false, tid);
           if (st == MO_STATUS_OK) {
             solve_for_update(w, n, k, m, (T)0, false, tid);
             for (int i = tid; i < n; i += kThreads) x[i] = w.delta[i];
@@ -657,7 +747,7 @@ __global__ __launch_bounds__(kMaxThreads) void kkt_generic_kernel(const KernelAr
         rec[0] = w.red[0]; rec[1] = w.red[1]; rec[2] = w.red[2]; rec[3] = w.red[3];
         __syncthreads();
         // Iterate, qp.cc:153-201 (its leading EvaluateKKTConditions would recompute the residual we already hold)
-        st = newton_direction(w, n, k, m, mu, sp.barrier_strategy, (T)0.995, rec + 8, tid);
+        st = newton_direction<T, TG, R>(w, n, k, m, mu, sp.barrier_strategy, (T)0.995, rec + 8, tid);
         if (st != MO_STATUS_OK) break;
         update_state(w, n, k, m, rec[9], rec[10], tid);
         load_qp(w, n, k, Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
@@ -790,7 +880,8 @@ __global__ __launch_bounds__(kMaxThreads) void nullspace_kernel(const KernelArgs
     for (int q = tid; q < k; q += kThreads) w.beq[q] = bp[q];
     if (j_level) {
       const T lam = a.lambda_vec ? ((const T*)a.lambda_vec)[p * a.lambda_vec_stride] : (T)a.lambda;
-      accumulate_jtj(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
+      if (kThreads == 64) accumulate_jtj<T, 8, 6>(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
+      else accumulate_jtj<T, 16, 9>(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
     }
     for (int l = wave; l < n; l += kWaves)   // selfadjointView<Lower>: mirror the lower triangle
       for (int i = lane; i < l; i += 64) op.G(i, l) = op.G(l, i);
@@ -973,7 +1064,7 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
   const size_t lds = generic_lds_bytes(a, elem);
   static const int env_threads = [] { const char* e = getenv("MO_GENERIC_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob
   int threads = (a.n + a.k <= 48) ? 64 : kMaxThreads;  // measured: cfg 2 (P = 36) 8.5 M vs 6.8 M steps/s, cfg 3 (P = 72) 0.75 M vs 1.9 M
-  if (env_threads == 64 || env_threads == 128 || env_threads == 256) threads = env_threads;
+  if (env_threads == 256) threads = 256;  // (the register-distributed factorisation wants an 8 x 8 or a 16 x 16 thread grid)
   const int max_per_cu = 32 / (threads / 64);
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
   if (per_cu < 1) per_cu = 1;
@@ -982,24 +1073,33 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
   if (grid > a.batch) grid = a.batch;
   if (grid < 1) grid = 1;
   hipError_t e = hipSuccess;
-#define MO_LAUNCH_GENERIC(TYPE, MODE_)                                                                               \
-  do {                                                                                                               \
-    e = hipFuncSetAttribute((const void*)kkt_generic_kernel<TYPE, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                               \
-    if (e != hipSuccess) return e;                                                                                   \
-    hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_>), dim3((unsigned)grid), dim3(threads), lds, stream, a);     \
+  const int P = a.n + a.k;
+#define MO_LAUNCH_GENERIC(TYPE, MODE_, TG_, R_)                                                                               \
+  do {                                                                                                                       \
+    e = hipFuncSetAttribute((const void*)kkt_generic_kernel<TYPE, MODE_, TG_, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                                       \
+    if (e != hipSuccess) return e;                                                                                           \
+    hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_, TG_, R_>), dim3((unsigned)grid), dim3(threads), lds, stream, a);      \
+  } while (0)
+#define MO_LAUNCH_FACTORISING(TYPE, MODE_)                     \
+  do {                                                         \
+    if (threads == 64) MO_LAUNCH_GENERIC(TYPE, MODE_, 8, 6);   \
+    else if (P <= 80) MO_LAUNCH_GENERIC(TYPE, MODE_, 16, 5);   \
+    else if (P <= 144) MO_LAUNCH_GENERIC(TYPE, MODE_, 16, 9);  \
+    else MO_LAUNCH_GENERIC(TYPE, MODE_, 16, 12);               \
   } while (0)
 #define MO_DISPATCH_MODE(TYPE)                                          \
   switch (a.mode) {                                                     \
-    case MODE_LINEARIZE: MO_LAUNCH_GENERIC(TYPE, MODE_LINEARIZE); break; \
-    case MODE_RESIDUAL: MO_LAUNCH_GENERIC(TYPE, MODE_RESIDUAL); break;   \
-    case MODE_STEP: MO_LAUNCH_GENERIC(TYPE, MODE_STEP); break;           \
-    case MODE_ITERATE: MO_LAUNCH_GENERIC(TYPE, MODE_ITERATE); break;     \
-    case MODE_SOLVE: MO_LAUNCH_GENERIC(TYPE, MODE_SOLVE); break;         \
+    case MODE_LINEARIZE: MO_LAUNCH_FACTORISING(TYPE, MODE_LINEARIZE); break;   \
+    case MODE_RESIDUAL: MO_LAUNCH_FACTORISING(TYPE, MODE_RESIDUAL); break;     \
+    case MODE_STEP: MO_LAUNCH_FACTORISING(TYPE, MODE_STEP); break;       \
+    case MODE_ITERATE: MO_LAUNCH_FACTORISING(TYPE, MODE_ITERATE); break; \
+    case MODE_SOLVE: MO_LAUNCH_FACTORISING(TYPE, MODE_SOLVE); break;     \
     default: return hipErrorInvalidValue;                               \
   }
   if (dtype == MO_F64) { MO_DISPATCH_MODE(double) } else { MO_DISPATCH_MODE(float) }
 #undef MO_DISPATCH_MODE
+#undef MO_LAUNCH_FACTORISING
 #undef MO_LAUNCH_GENERIC
   return hipGetLastError();
 }

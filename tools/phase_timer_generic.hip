@@ -76,5 +76,9 @@ int main(int argc, char** argv) {
            h[11] / (double)h[8] / 100.0, h[12] / 100.0, (tot / h[8]) / (h[11] / (double)h[8] / 100.0) / 1e3);
     printf("  total %.0f ticks per problem per wave (s_memtime ticks: 100 MHz constant clock => x ~21 for core cycles)\n", tot / batch);
   }
+  unsigned long long nd[8];
+  CK(hipMemcpyFromSymbol(nd, HIP_SYMBOL(mo::g_nd_stamps), sizeof(nd)));
+  printf("  inside newton_direction (3 launches summed): assemble + factorise %llu, rhs + solve + ds/dz %llu ticks per problem\n",
+         nd[0] / (3 * batch), nd[1] / (3 * batch));
   return 0;
 }
