@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libminiopt_hip.so")
+LIB_PATH = os.environ.get("MO_LIB_PATH") or os.path.join(_HERE, "lib", "libminiopt_hip.so")  # MO_LIB_PATH: A/B runs against another build
 CSRC = os.path.join(_HERE, "csrc")
 
 MO_OK = 0
