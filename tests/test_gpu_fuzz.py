@@ -1,0 +1,57 @@
+"""Randomised sweep over (n, k, m, m_r) x the layouts of J the C ABI accepts (packed, a leading dimension beyond n, column-major with
+and without padding, rows that are only 8-byte aligned): every case must run on the fused kernels, the step must match the oracle to
+1e-9 and the Solve must follow the packed-layout Solve."""
+import numpy as np
+import pytest
+import torch
+
+from mini_opt_amd import qp as Q
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dt=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_shapes_and_layouts(seed):
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for trial in range(40):
+        n = int(rng.integers(2, 129)); k = int(rng.integers(0, min(16, n))); m = int(rng.integers(0, 65)); m_r = int(rng.integers(1, 300)); B = 5
+        J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+        A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+        cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+        x = rng.uniform(-0.1, 0.1, (B, n)); sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+        vars_ = np.concatenate([x, sl, y, z], axis=1); mu = np.full(B, 0.05)
+        lam = 0.3 if m_r < n else 1e-3
+        ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, J=J, r=r, lam=lam, A_eq=A if k else None, b_eq=b if k else None,
+            cons_var=cv if m else None, cons_a=ca if m else None, cons_b=cb if m else None, vars_=vars_, mu=mu)
+        which = int(rng.integers(0, 4))
+        kw = {}
+        if which == 0: Jt = T(J)
+        elif which == 1:
+            pad = int(rng.integers(1, 9)); wide = np.full((B, m_r, n + pad), 9.9); wide[:, :, :n] = J; Jt = T(wide)
+        elif which == 2:
+            pad = int(rng.integers(0, 5)); colw = np.full((B, n, m_r + pad), -9.9); colw[:, :, :m_r] = J.transpose(0, 2, 1); Jt = T(colw); kw = dict(J_layout="col", J_rows=m_r)
+        else:
+            flat = torch.zeros(B * m_r * n + 1, dtype=torch.float64, device="cuda:0"); flat[1:] = T(J).reshape(-1); Jt = flat[1:].view(B, m_r, n)
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=Jt, r=T(r), lam=lam, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
+                           cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca) if m else None, cons_b=T(cb) if m else None, **kw)
+        s = Q.QPInteriorPointSolver(prob)
+        assert s.step_kernel().startswith("fused"), (n, k, m, m_r, which, s.step_kernel())
+        s.SetVariables(T(vars_))
+        delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+        assert torch.all(status == 0) and np.all(ref_status == 0), (n, k, m, m_r, which)
+        err = (np.abs(delta.cpu().numpy() - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+        worst = max(worst, err)
+        assert err < 1e-9, (n, k, m, m_r, which, err)
+        out = s.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=10, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
+        assert torch.all(out.status == 0), (n, k, m, m_r, which)
+        sg = Q.QPInteriorPointSolver(Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
+                           cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca) if m else None, cons_b=T(cb) if m else None))
+        og = sg.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=10, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
+        same = (out.num_iterations == og.num_iterations) & (out.termination_state == og.termination_state)
+        assert same.float().mean() >= 0.8, (n, k, m, m_r, which)
