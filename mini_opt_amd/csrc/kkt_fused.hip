@@ -988,6 +988,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  // Start stagger.  Every problem costs the same, so the waves that share a SIMD (waves w, w + 4, w + 8 of the workgroup) would march
+  // through the phases in lockstep for the whole launch -- three J streams together, then three dependent pivot chains together.  Delaying
+  // the second and third wave of each SIMD once, by about a third of a problem each (a.stagger units of 127 x 64 cycles), keeps one wave
+  // in the matrix-bound phase while another is in the sweeps: +1.4 % at cfg 3 (A/B on one box), nothing at cfg 2.
+  if (a.stagger > 0) {
+    const int slot = wave >> 2;
+    for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   int chunk = chunk_for(0);
   long long p = uniform64(take_ticket(chunk));
   long long chunk_end = p + chunk;
@@ -1973,7 +1981,11 @@ const char* fused_name(const KernelArgs& a, int) {
   return a.n > 96 ? "fused_mfma_f64_n128" : a.n > 64 ? "fused_mfma_f64_n96" : a.n > 32 ? "fused_mfma_f64_n64" : "fused_mfma_f64_n32";
 }
 
-hipError_t launch_fused(const KernelArgs& a, int, int num_cus, hipStream_t stream) {
+hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t stream) {
+  KernelArgs a = a_in;
+  static const int env_stagger = [] { const char* e = getenv("MO_FUSED_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
+  // the 64-variable grid of the step kernel with J-level input (the BASELINE configs[2] / [4] shape); measured neutral elsewhere
+  a.stagger = env_stagger >= 0 ? env_stagger : ((a.mode == MODE_STEP && a.J && a.n > 32 && a.n <= 64) ? 4 : 0);
   // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
   static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();

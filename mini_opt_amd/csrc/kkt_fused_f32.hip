@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  if (a.stagger > 0) {  // start stagger between the waves that share a SIMD (see kkt_fused.hip): equal-cost problems keep waves in lockstep
+    const int slot = wave >> 2;
+    for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   int chunk = chunk_for(0);
   long long p = uniform64(take_ticket(chunk));
   long long chunk_end = p + chunk;
@@ -478,7 +482,10 @@ bool fused_f32_supported(const KernelArgs& a, int dtype) {
 
 const char* fused_f32_name(const KernelArgs& a) { return a.n == 128 ? "fused_mfma_f32_n128" : "fused_mfma_f32_n64"; }
 
-hipError_t launch_fused_f32(const KernelArgs& a, int num_cus, hipStream_t stream) {
+hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t stream) {
+  KernelArgs a = a_in;
+  static const int env_stagger = [] { const char* e = getenv("MO_FUSED_F32_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
+  a.stagger = env_stagger >= 0 ? env_stagger : 0;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
