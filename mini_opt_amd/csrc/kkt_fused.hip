@@ -1142,6 +1142,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     MO_STAMP(2);
     // ---- P5: block elimination with 16x16 pivot blocks
     __builtin_amdgcn_sched_barrier(0);
+    // The dependent pivot chains get issue priority over the J streams of the other waves (those always have an MFMA ready and fill
+    // whatever is left): +0.4 % on two boxes; priority on the J stream instead: -0.8 %.
+    if (a.chain_prio) __builtin_amdgcn_s_setprio(1);
     bool ok = true;
     if constexpr (SW == 6) {
       ok = block_eliminate_lookahead<NT>(U, k, g, j);
@@ -1237,6 +1240,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       if (ka->status) ka->status[p] = st;
     }
     lds_fence();  // LDS vectors are re-initialised by the next problem
+    if (a.chain_prio) __builtin_amdgcn_s_setprio(0);
     MO_STAMP(6);
     if (last_of_chunk) {
       p = uniform64(next_ticket);
@@ -1985,7 +1989,9 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   KernelArgs a = a_in;
   static const int env_stagger = [] { const char* e = getenv("MO_FUSED_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
   // the 64-variable grid of the step kernel with J-level input (the BASELINE configs[2] / [4] shape); measured neutral elsewhere
-  a.stagger = env_stagger >= 0 ? env_stagger : ((a.mode == MODE_STEP && a.J && a.n > 32 && a.n <= 64) ? 4 : 0);
+  const bool headline_shape = a.mode == MODE_STEP && a.J && a.n > 32 && a.n <= 64;
+  a.stagger = env_stagger >= 0 ? (env_stagger & 0xff) : (headline_shape ? 4 : 0);
+  a.chain_prio = env_stagger >= 0 ? ((env_stagger >> 8) & 1) : (headline_shape ? 1 : 0);   // MO_FUSED_STAGGER = units + 256 * priority
   // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
   static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();

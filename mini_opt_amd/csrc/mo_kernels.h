@@ -53,7 +53,8 @@ struct KernelArgs {
   const int* skip; long long skip_stride;
   // fused kernel: device work counter (plan-owned, zeroed on the launch stream before every launch)
   unsigned long long* ticket;
-  int stagger;  // fused step kernel: start offset between the waves that share a SIMD, in units of 127 x 64 cycles (set by launch_fused)
+  int stagger;     // fused step kernel: start offset between the waves that share a SIMD, in units of 127 x 64 cycles (set by launch_fused)
+  int chain_prio;  // fused step kernel: s_setprio 1 while a wave is in the elimination / substitution chains
   // diagnostics only (tools/phase_timer.hip builds kkt_fused.hip with MO_FUSED_STAMPS); NULL in the product
   unsigned long long* debug;
 };
