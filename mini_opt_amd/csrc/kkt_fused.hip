@@ -198,10 +198,11 @@ template <int NT, bool QPL> __device__ inline void pad_diag(int j, int nn, doubl
     v[c] = nat >= nn ? 1.0 : 0.0;
   }
 }
-// [A_eq^T | .] tile column: element (row r = g + 4t of block c, column j < k) = A_eq(j, variable of position 16c + r).
-template <int NT, bool QPL>
-__device__ inline void load_a_tiles(const double* Ap, int A_ld, int k, int nn, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)]) {
-  constexpr int NB = NT + 1;
+// [A_eq^T | .] tile columns: element (row r = g + 4t of block c, column j) of y tile q = A_eq(16q + j, variable of position 16c + r).
+// NY y tiles carry up to 16 NY - 1 equality rows (column 15 of the LAST tile column is the right-hand side).
+template <int NT, bool QPL, int NY = 1>
+__device__ inline void load_a_tiles(const double* Ap, int A_ld, int k, int nn, int g, int j, d4 (&U)[(NT + NY) * (NT + NY)]) {
+  constexpr int NB = NT + NY;
   const int col_l = (QPL ? 1 : 2) * g;                             // per-lane part of the column index
   const double* Al = Ap + j + (size_t)col_l * A_ld;
 #pragma unroll
@@ -209,16 +210,18 @@ __device__ inline void load_a_tiles(const double* Ap, int A_ld, int k, int nn, i
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int col_u = QPL ? (16 * c + 4 * t) : (32 * (c >> 1) + 8 * t + (c & 1));  // wave-uniform part
-      U[c * NB + NT][t] = (j < k && col_u + col_l < nn) ? Al[(size_t)col_u * A_ld] : 0.0;
+#pragma unroll
+      for (int q = 0; q < NY; ++q)
+        U[c * NB + NT + q][t] = (16 * q + j < k && col_u + col_l < nn) ? Al[16 * q + (size_t)col_u * A_ld] : 0.0;
     }
   }
 }
 // QP-level cost: the G tiles come straight from the caller's column-major G (only its lower triangle is read, qp.cc:289):
 // tile (a, b), element (r, j) = G(16b + j, 16a + r) for b > a (128-byte rows across the lanes), mirrored inside diagonal tiles.
-template <int NT>
-__device__ inline void load_g_tiles(const double* G, int ld, const double* cg, int nn, int g, int j, d4 (&U)[(NT + 1) * (NT + 1)],
+template <int NT, int NY = 1>
+__device__ inline void load_g_tiles(const double* G, int ld, const double* cg, int nn, int g, int j, d4 (&U)[(NT + NY) * (NT + NY)],
                                     double (&cvec)[NT]) {
-  constexpr int NB = NT + 1;
+  constexpr int NB = NT + NY;
 #pragma unroll
   for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
@@ -510,10 +513,10 @@ template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int 
 // scalar unit: base + column part; one VGPR holds the lane part g * row_stride + 2j * column_stride).  2 NT + 1 DMAs per group, operand c
 // at dwords [2c][lane] and [2c+1][lane] of the slot.  The memory system sees 4-byte pieces: this is the flexible path, not the fast one.
 constexpr int JMODE_VECTOR = 0, JMODE_FLAT = 1, JMODE_GATHER = 2;
-template <int NT, int D, int JMODE = JMODE_VECTOR>
+template <int NT, int D, int JMODE = JMODE_VECTOR, int NY = 1>
 struct JStream {
   static constexpr bool FLAT = JMODE == JMODE_FLAT, GATHER = JMODE == JMODE_GATHER;
-  static constexpr int N = 16 * NT, NB = NT + 1, NH = NT / 2, NI = GATHER ? 2 * NT : (FLAT ? N / 8 : NH), DPS = NI + 1, SLOT = NH * 1024 + 64;
+  static constexpr int N = 16 * NT, NB = NT + NY, NH = NT / 2, NI = GATHER ? 2 * NT : (FLAT ? N / 8 : NH), DPS = NI + 1, SLOT = NH * 1024 + 64;
   static_assert((D - 1) * DPS <= 63, "vmcnt is a 6-bit counter");
   static_assert(D >= 2 && D <= 8, "ring depth");
   const char* jbase;   // wave-uniform: row 4s of J
@@ -695,13 +698,15 @@ struct JStream {
 
 // Block LDL^T with 16x16 pivot blocks over the (NT+1) x (NT+1) upper block triangle of tiles (the last block column is
 // [A_eq^T | rhs]).  Afterwards the diagonal tiles hold -T^-1, the off-diagonal tiles their forward-eliminated values.
-template <int NT, int SW>
-__device__ inline bool block_eliminate(d4 (&U)[(NT + 1) * (NT + 1)], int k, int g, int j) {
-  constexpr int NB = NT + 1;
+// Pivots of diagonal tile pa: 16 for the x tiles and for every y tile but the last, which holds the remaining k - 16 (NY - 1) equality rows.
+template <int NT, int NY> __device__ inline int tile_pivots(int pa, int k) { return pa < NT + NY - 1 ? 16 : k - 16 * (NY - 1); }
+template <int NT, int SW, int NY = 1>
+__device__ inline bool block_eliminate(d4 (&U)[(NT + NY) * (NT + NY)], int k, int g, int j) {
+  constexpr int NB = NT + NY;
   bool ok = true;
 #pragma unroll
   for (int pa = 0; pa < NB; ++pa) {
-    ok = sweep_tile<SW>(U[pa * NB + pa], pa < NT ? 16 : k, g, j) && ok;
+    ok = sweep_tile<SW>(U[pa * NB + pa], tile_pivots<NT, NY>(pa, k), g, j) && ok;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pc = pa + 1; pc < NB; ++pc) {
@@ -818,22 +823,22 @@ __device__ inline bool block_eliminate_lookahead(d4 (&U)[(NT + 1) * (NT + 1)], i
 }
 
 // Backward substitution after block_eliminate; xb[c] = solution at permuted position 16c + j (replicated over g),
-// xb[NT] = the y-block solution in lanes j < k.
-template <int NT>
-__device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k, int j, double (&xb)[NT + 1]) {
-  constexpr int NB = NT + 1;
+// xb[NT + q] = the solution of y tile q in lanes 16 q + j < k.
+template <int NT, int NY = 1>
+__device__ inline void back_substitute(const d4 (&U)[(NT + NY) * (NT + NY)], int k, int j, double (&xb)[NT + NY]) {
+  constexpr int NB = NT + NY, L = NB - 1;
   {
-    double v = 0.0;  // sits in column kRC of the swept y tile: element (q, kRC) at lane (q & 3, kRC), register q >> 2
+    double v = 0.0;  // sits in column kRC of the swept LAST y tile: element (q, kRC) at lane (q & 3, kRC), register q >> 2
     const int src = (16 * (j & 3) + kRC) * 4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const double w = bpermute_f64(src, U[NT * NB + NT][t]);
+      const double w = bpermute_f64(src, U[L * NB + L][t]);
       if ((j >> 2) == t) v = w;
     }
-    xb[NT] = (j < k) ? v : 0.0;
+    xb[L] = (16 * (NY - 1) + j < k) ? v : 0.0;
   }
 #pragma unroll
-  for (int pa = NT - 1; pa >= 0; --pa) {
+  for (int pa = L - 1; pa >= 0; --pa) {
     double vt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -841,7 +846,7 @@ __device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k
 #pragma unroll
       for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
       pt = row_sum(pt);                                  // sum over the row's 16 lanes (columns of the tile row)
-      vt[t] = row_bcast64<kRC>(U[pa * NB + NT][t]) - pt;  // forward-eliminated rhs minus the already solved blocks
+      vt[t] = row_bcast64<kRC>(U[pa * NB + L][t]) - pt;   // forward-eliminated rhs minus the already solved blocks
     }
     double q = 0.0;
 #pragma unroll
@@ -855,17 +860,19 @@ __device__ inline void back_substitute(const d4 (&U)[(NT + 1) * (NT + 1)], int k
 // forward-eliminated values) -- what Mehrotra's corrector needs: same matrix, new rhs.  Vectors are V16 (value at lane j, replicated
 // over g); the row-layout copies a tile product needs go through a 16-double LDS hop.  rb[] is consumed; the forward-eliminated
 // blocks are parked in rbuf_x / rbuf_y for the substitution.  xb[c] = solution at permuted position 16c + j, xb[NT] = the y block.
-template <int NT>
-__device__ inline void solve_second_rhs(const d4 (&U)[(NT + 1) * (NT + 1)], int k, int g, int j, double (&rb)[NT + 1], double* hop,
-                                        double* rbuf_x, double* rbuf_y, double (&xb)[NT + 1]) {
-  constexpr int NB = NT + 1;
-  rb[NT] = (j < k) ? rb[NT] : 0.0;  // lanes beyond the k equalities carry the first solve's leftovers in the tiles: keep them out
+template <int NT, int NY = 1>
+__device__ inline void solve_second_rhs(const d4 (&U)[(NT + NY) * (NT + NY)], int k, int g, int j, double (&rb)[NT + NY], double* hop,
+                                        double* rbuf_x, double* rbuf_y, double (&xb)[NT + NY]) {
+  constexpr int NB = NT + NY, L = NB - 1;
+  // lanes beyond the k equalities carry the first solve's leftovers in the tiles: keep them out
+#pragma unroll
+  for (int q = 0; q < NY; ++q) rb[NT + q] = (16 * q + j < k) ? rb[NT + q] : 0.0;
 #pragma unroll
   for (int pa = 0; pa < NB; ++pa) {  // forward: r_b += U_ab^T (-T_a^-1 r_a), b > a
-    if (pa == NT) rb[NT] = (j < k) ? rb[NT] : 0.0;
-    if (g == 0) { hop[j] = rb[pa]; (pa < NT ? rbuf_x + 16 * pa : rbuf_y)[j] = rb[pa]; }
+    if (pa >= NT) rb[pa] = (16 * (pa - NT) + j < k) ? rb[pa] : 0.0;
+    if (g == 0) { hop[j] = rb[pa]; (pa < NT ? rbuf_x + 16 * pa : rbuf_y + 16 * (pa - NT))[j] = rb[pa]; }
     lds_fence();
-    if (pa < NT) {
+    if (pa < L) {
       double q = 0.0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], hop[g + 4 * t], q);
@@ -887,22 +894,22 @@ __device__ inline void solve_second_rhs(const d4 (&U)[(NT + 1) * (NT + 1)], int 
     }
   }
 #pragma unroll
-  for (int pa = NT; pa >= 0; --pa) {  // backward, as back_substitute() but with the rhs read from LDS
-    const double* rsrc = pa < NT ? rbuf_x + 16 * pa : rbuf_y;
+  for (int pa = L; pa >= 0; --pa) {  // backward, as back_substitute() but with the rhs read from LDS
+    const double* rsrc = pa < NT ? rbuf_x + 16 * pa : rbuf_y + 16 * (pa - NT);
     double vt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       double pt = 0.0;
 #pragma unroll
       for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
-      if (pa < NT) pt = row_sum(pt);
+      if (pa < L) pt = row_sum(pt);
       vt[t] = rsrc[g + 4 * t] - pt;
     }
     double q = 0.0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);
     xb[pa] = -cross_row_sum(q);
-    if (pa == NT) xb[NT] = (j < k) ? xb[NT] : 0.0;
+    if (pa >= NT) xb[pa] = (16 * (pa - NT) + j < k) ? xb[pa] : 0.0;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -911,13 +918,13 @@ __device__ inline void solve_second_rhs(const d4 (&U)[(NT + 1) * (NT + 1)], int 
 // NT = n / 16 (2 or 4), WPS = waves per SIMD the register budget is sized for.  k <= 15 (index 15 of the y tile carries the right-hand side), m <= 64 MC are
 // checked by fused_supported().
 // MC = constraint slots per lane (m <= 64 MC).
-template <int NT, int WPS, int MC = 1> struct FusedCfg {
+template <int NT, int WPS, int MC = 1, int NY = 1> struct FusedCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;                 // 16-byte J loads per lane per 4-row group
   static constexpr int DPS = NH + 1;                // LDS-DMA instructions per 4-row group (J pieces + 32 B of r)
   static constexpr int SLOT = NH * 1024 + 64;       // ring slot: 4 rows of J (lane-linear) + r[4s..4s+3]
   static constexpr int MCAP = 64 * MC;
-  static constexpr int VEC = (3 * N + 4 * MCAP + MCAP / 2 + 32) * 8;  // xs, diagS|rp, rhsS|dxs, cons a/b/s/z, cons var (int), y[16], b_eq[16]
+  static constexpr int VEC = (3 * N + 4 * MCAP + MCAP / 2 + 32 * NY) * 8;  // xs, diagS|rp, rhsS|dxs, cons a/b/s/z, cons var (int), y[16 NY], b_eq[16 NY]
   static constexpr int D_FIT = ((160 * 1024) / (4 * WPS) - VEC) / SLOT;  // what the 160 KiB of a CU leave per wave
   static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 7) : (WPS >= 4 ? 4 : 8));
   static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);  // ring depth (4-row groups in flight per wave), LDS-limited
@@ -927,11 +934,11 @@ template <int NT, int WPS, int MC = 1> struct FusedCfg {
 
 // One workgroup of 4*WPS independent waves per CU (so that exactly WPS waves sit on every SIMD).  The waves never
 // synchronise with each other; each owns its slice of the workgroup's LDS.
-template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR, int NY = 1>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const KernelArgs a) {
-  using C = FusedCfg<NT, WPS, MC>;
+  using C = FusedCfg<NT, WPS, MC, NY>;
   constexpr int MCAP = C::MCAP;
-  constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
+  constexpr int N = C::N, NB = NT + NY, LT = NB - 1, SLOT = C::SLOT, D = C::D;  // LT: the tile column that carries the right-hand side
   constexpr int WAVES = 4 * WPS;
 
   // ONE shared array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads)
@@ -949,7 +956,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   double* const cZ = cS + MCAP;
   int* const cV = reinterpret_cast<int*>(cZ + MCAP);
   double* const yb = cZ + MCAP + MCAP / 2;
-  double* const bb = yb + 16;
+  double* const bb = yb + 16 * NY;
   const unsigned ring_base = (unsigned)(uintptr_t)smem;           // LDS byte address of the ring (low 32 bits of the flat address)
   const unsigned vec_base = ring_base + D * SLOT;                 // LDS byte address of xs
 
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const double* vp = (const double*)ka->vars + p * ka->vars_stride;
 
     // The ring is filled FIRST: the J stream's memory latency then overlaps the address arithmetic and the small loads of P0.
-    JStream<NT, D, JMODE> stream;
+    JStream<NT, D, JMODE, NY> stream;
     if (!QPL) {
       stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
       stream.prologue();
@@ -1045,10 +1052,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     }
     if (k > 0) {
       dma_doubles(vp + nn + m_lay, vec_base + (3 * N + 4 * MCAP + MCAP / 2) * 8, k, lane);   // y
-      dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 4 * MCAP + MCAP / 2 + 16) * 8, k, lane);  // b_eq
+      dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 4 * MCAP + MCAP / 2 + 16 * NY) * 8, k, lane);  // b_eq
     }
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
-    load_a_tiles<NT, QPL>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, nn, g, j, U);
+    load_a_tiles<NT, QPL, NY>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, nn, g, j, U);
 
     MO_STAMP(0);
     // ---- P1: stream J once through the LDS-DMA ring; G = J^T J on the matrix cores (upper block triangle of tiles),
@@ -1059,7 +1066,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
     double cvec[NT];  // c (= J^T r) at position 16c + j (replicated over g)
     if (QPL) {
-      load_g_tiles<NT>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, nn, g, j, U, cvec);
+      load_g_tiles<NT, NY>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, nn, g, j, U, cvec);
     } else {
       stream.run(U, cpart);
 #pragma unroll
@@ -1119,11 +1126,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 
     // ---- P2/P4: lambda + Sigma on the diagonal tiles (position (r, r): lanes with j == g + 4t); rhs into column kRC
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {  // y diagonal tile = [0, -b_eq; -b_eq^T, 0]: (r, kRC) = -b[r], (kRC, q) = -b[q]
+    for (int t = 0; t < 4; ++t) {  // last y diagonal tile = [0, -b_eq; -b_eq^T, 0]: (r, kRC) = -b[r], (kRC, q) = -b[q]
+      constexpr int e0 = 16 * (NY - 1);   // first equality row of the last y tile
       double v = 0.0;
-      if (j == kRC) v = (g + 4 * t < k) ? -bb[g + 4 * t] : 0.0;
-      if (g + 4 * t == kRC) v = (j < k) ? -bb[j] : 0.0;
-      U[NT * NB + NT][t] = v;
+      if (j == kRC) v = (e0 + g + 4 * t < k) ? -bb[e0 + g + 4 * t] : 0.0;
+      if (g + 4 * t == kRC) v = (e0 + j < k) ? -bb[e0 + j] : 0.0;
+      U[LT * NB + LT][t] = v;
+      if constexpr (NY == 2) {          // the full y tile in front of it: right-hand side -b_eq[0 .. 15] in column kRC of tile (NT, LT)
+        if (j == kRC) U[NT * NB + LT][t] = -bb[g + 4 * t];
+      }
     }
     const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
     const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // nonlinear.cc:187-189 (a given G already carries it)
@@ -1135,7 +1146,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       for (int t = 0; t < 4; ++t) {
         U[c * NB + c][t] += (j == g + 4 * t) ? (lam + dS[c] + padv[c]) : 0.0;
         const double rv = rp[16 * c + g + 4 * t];
-        if (j == kRC) U[c * NB + NT][t] = rv;
+        if (j == kRC) U[c * NB + LT][t] = rv;
       }
     }
 
@@ -1151,7 +1162,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     } else {
 #pragma unroll
     for (int pa = 0; pa < NB; ++pa) {
-      ok = sweep_tile<SW>(U[pa * NB + pa], pa < NT ? 16 : k, g, j) && ok;
+      ok = sweep_tile<SW>(U[pa * NB + pa], tile_pivots<NT, NY>(pa, k), g, j) && ok;
       __builtin_amdgcn_sched_barrier(0);
       MO_STAMP(3);
 #pragma unroll
@@ -1168,7 +1179,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     __builtin_amdgcn_sched_barrier(0);
     // ---- P6: backward substitution; xb[c] = solution at permuted position 16c + j (replicated over g)
     double xb[NB];
-    back_substitute<NT>(U, k, j, xb);
+    back_substitute<NT, NY>(U, k, j, xb);
 
     MO_STAMP(5);
     // ---- P7: direction, step lengths, status
@@ -1205,8 +1216,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     }
     ap = cross_row_min(row_min(ap));
     ad = cross_row_min(row_min(ad));
-    const double dyv = (j < k) ? (-xb[NT] - yb[j]) : 0.0;                           // y+ - y
-    finite = finite && (fabs(dyv) < INFINITY);
+    double dyv[NY];                                                                 // y+ - y, equality row 16 q + j
+#pragma unroll
+    for (int q = 0; q < NY; ++q) {
+      dyv[q] = (16 * q + j < k) ? (-xb[NT + q] - yb[16 * q + j]) : 0.0;
+      finite = finite && (fabs(dyv[q]) < INFINITY);
+    }
     int st = MO_STATUS_OK;
     if (!__all(finite)) st = MO_STATUS_NONFINITE;
     if (!ok) st = MO_STATUS_FACTORIZATION_FAILED;
@@ -1219,7 +1234,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #pragma unroll
       for (int c = 0; c < NT; ++c) outv[c] = st == MO_STATUS_OK ? dxv[c] : nanv;
       stv_n<NT, QPL>(dp, j, nn, outv);
-      if (j < k) dp[nn + m_lay + j] = st == MO_STATUS_OK ? dyv : nanv;
+#pragma unroll
+      for (int q = 0; q < NY; ++q)
+        if (16 * q + j < k) dp[nn + m_lay + 16 * q + j] = st == MO_STATUS_OK ? dyv[q] : nanv;
     }
     if (no_ineq) {  // ds = dz = 0 (qp.cc:366-386 writes only dx, dy)
       for (int ix = lane; ix < m_lay; ix += 64) { dp[nn + ix] = st == MO_STATUS_OK ? 0.0 : nanv; dp[nn + m_lay + k + ix] = st == MO_STATUS_OK ? 0.0 : nanv; }
@@ -1351,12 +1368,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
 // one-shot step kernel -- solves for the DIRECTION with the residual as right-hand side, exactly the reference's system
 // (qp.cc:255-268, 337-363), so the loop keeps Newton's self-correcting behaviour down to tight KKT tolerances.
 // All three BarrierStrategy values; PREDICTOR_CORRECTOR pushes its second right-hand side through the first solve's factors.
-template <int NT, int WPS, int MC = 1> struct SolveCfg {
+template <int NT, int WPS, int MC = 1, int NY = 1> struct SolveCfg {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 2;
   static constexpr int SLOT = NH * 1024 + 64;
   static constexpr int MCAP = 64 * MC;                    // constraint slots: MC per lane
-  static constexpr int VEC = (6 * N + 32) * 8;            // xs, xp, azS, diagS, rhoS, tmp, ysmall[32]
+  static constexpr int VEC = (6 * N + 32 * NY) * 8;       // xs, xp, azS, diagS, rhoS, tmp, ysmall[32 NY]
   static constexpr int D_FIT = ((160 * 1024) / (4 * WPS) - VEC) / SLOT;
   static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
   static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);
@@ -1366,10 +1383,11 @@ template <int NT, int WPS, int MC = 1> struct SolveCfg {
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
 
-template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR, int NY = 1>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
-  using C = SolveCfg<NT, WPS, MC>;
-  constexpr int N = C::N, NB = NT + 1, SLOT = C::SLOT, D = C::D;
+  using C = SolveCfg<NT, WPS, MC, NY>;
+  constexpr int N = C::N, NB = NT + NY, LT = NB - 1, SLOT = C::SLOT, D = C::D;  // LT: the tile column that carries the right-hand side
+  constexpr int YN = 16 * NY;                                                    // equality rows the y tiles hold
   constexpr int WAVES = 4 * WPS;
 
   __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
@@ -1381,7 +1399,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   double* const diagS = azS + N;                                  // barrier diagonal per variable
   double* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
   double* const tmp = rhoS + N;                                   // layout-conversion scratch (R <-> V16, natural <-> permuted)
-  double* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
+  double* const ysm = tmp + N;                                    // [0, YN): y ; [YN, 2 YN): -r_pe
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
   const int k = a.k, m = a.m, m_r = a.m_r;
@@ -1442,12 +1460,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         cb[ci] = ((const double*)a.cons_b)[p * a.cons_stride + ix];
       }
     }
-    double b_col = 0.0;
-    if (j < k) b_col = ((const double*)a.b + p * a.b_stride)[j];
+    double b_col[NY];
+#pragma unroll
+    for (int q = 0; q < NY; ++q) b_col[q] = (16 * q + j < k) ? ((const double*)a.b + p * a.b_stride)[16 * q + j] : 0.0;
     const double* const Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
 
     // ---- state: x in the permuted V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
-    double xv[NT], yv = 0.0, cs[MC], cz[MC];
+    double xv[NT], yv[NY], cs[MC], cz[MC];  // yv[q]: equality row 16 q + j
+#pragma unroll
+    for (int q = 0; q < NY; ++q) yv[q] = 0.0;
 #pragma unroll
     for (int c = 0; c < NT; ++c) xv[c] = 0.0;
 #pragma unroll
@@ -1457,7 +1478,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     const bool iterate_mode = a.mode == MODE_ITERATE || residual_mode;  // one Iterate (qp.cc:153-201) on the caller's state and mu
     if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
       ldv_n<NT, QPL>(vp, j, nn, xv);
-      if (j < k) yv = vp[nn + m + j];
+#pragma unroll
+      for (int q = 0; q < NY; ++q)
+        if (16 * q + j < k) yv[q] = vp[nn + m + 16 * q + j];
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci)
         if (lane + 64 * ci < m) { cs[ci] = vp[nn + lane + 64 * ci]; cz[ci] = vp[nn + m + k + lane + 64 * ci]; }
@@ -1550,7 +1573,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // kept in VGPRs across the factorisation (see the step kernel)
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
       // ---------------------------------------------------------------- part A: tiles, residual, norms
-      JStream<NT, D, JMODE> stream;
+      JStream<NT, D, JMODE, NY> stream;
       const bool stream_now = !QPL && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;  // wave-uniform, and hipcc must know it
       if (stream_now) {
         stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
@@ -1559,13 +1582,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       d4 U[NB * NB];
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-      load_a_tiles<NT, QPL>(Ap, a.A_ld, k, nn, g, j, U);
+      load_a_tiles<NT, QPL, NY>(Ap, a.A_ld, k, nn, g, j, U);
       // publish the state for the layout conversions below; zero the per-variable scatter arrays
       if (g == 0) {
         stv<NT, QPL>(xs, j, xv);
 #pragma unroll
         for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
-        ysm[j] = (j < k) ? yv : 0.0;
+#pragma unroll
+        for (int q = 0; q < NY; ++q) ysm[16 * q + j] = (16 * q + j < k) ? yv[q] : 0.0;
       }
       if (lane < N / 2) {
         azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0;
@@ -1574,7 +1598,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       double cvec[NT];
       if (QPL) {
-        load_g_tiles<NT>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, nn, g, j, U, cvec);
+        load_g_tiles<NT, NY>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, nn, g, j, U, cvec);
       } else if (stream_now) {
         double cpart[NT];
 #pragma unroll
@@ -1628,7 +1652,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           r_comp[ci] = cs[ci] * cz[ci];                                  // qp.cc:417
         }
       }
-      double r_d[NT], r_pe;
+      double r_d[NT], r_pe[NY];
       {
       // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
       // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
@@ -1639,10 +1663,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       for (int ra = 0; ra < NB; ++ra) {
         double vR[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vR[t] = ra < NT ? xp[16 * ra + g + 4 * t] : -ysm[g + 4 * t];
+        for (int t = 0; t < 4; ++t) vR[t] = ra < NT ? xp[16 * ra + g + 4 * t] : 0.0;
 #pragma unroll
         for (int b = ra; b < NB; ++b) {
-          if (ra == NT && b == NT) continue;  // the y diagonal block of K is zero
+          if (ra >= NT) continue;  // the y diagonal block of K is zero
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc1[b] = fma(U[ra * NB + b][t], vR[t], acc1[b]);
         }
@@ -1651,7 +1675,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           for (int t = 0; t < 4; ++t) {
             double pt = 0.0;
 #pragma unroll
-            for (int b = ra + 1; b < NB; ++b) pt = fma(U[ra * NB + b][t], b < NT ? xv[b] : ((j < k) ? -yv : 0.0), pt);
+            for (int b = ra + 1; b < NB; ++b) pt = fma(U[ra * NB + b][t], b < NT ? xv[b] : -yv[b < NT ? 0 : b - NT], pt);  // yv is zero on lanes beyond k
             pt = row_sum(pt);
             if (j == 0) tmp[16 * ra + g + 4 * t] = pt;
           }
@@ -1664,13 +1688,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
         for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
       }
-      r_pe = (j < k) ? cross_row_sum(acc1[NT]) + b_col : 0.0;                                              // qp.cc:408
+#pragma unroll
+      for (int q = 0; q < NY; ++q) r_pe[q] = (16 * q + j < k) ? cross_row_sum(acc1[NT + q]) + b_col[q] : 0.0;  // qp.cc:408
       {
         double t = 0.0;
 #pragma unroll
         for (int c = 0; c < NT; ++c) t = fma(r_d[c], r_d[c], t);
         n_rd2 = row_sum(t);
-        n_rpe2 = row_sum(r_pe * r_pe);
+        double t_pe = 0.0;
+#pragma unroll
+        for (int q = 0; q < NY; ++q) t_pe = fma(r_pe[q], r_pe[q], t_pe);
+        n_rpe2 = row_sum(t_pe);
         double s_rc2 = 0.0, s_rc1 = 0.0, s_rpi2 = 0.0;
 #pragma unroll
         for (int ci = 0; ci < MC; ++ci) { s_rc2 = fma(r_comp[ci], r_comp[ci], s_rc2); s_rc1 += r_comp[ci]; s_rpi2 = fma(r_pi[ci], r_pi[ci], s_rpi2); }
@@ -1684,7 +1712,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         double* ro = (double*)a.r_out + p * a.r_out_stride;
         if (g == 0) {
           stv_n<NT, QPL>(ro, j, nn, r_d);
-          if (j < k) ro[nn + m + j] = r_pe;
+#pragma unroll
+          for (int q = 0; q < NY; ++q)
+            if (16 * q + j < k) ro[nn + m + 16 * q + j] = r_pe[q];
         }
 #pragma unroll
         for (int ci = 0; ci < MC; ++ci)
@@ -1771,32 +1801,45 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[c]);          // -r_aug, position order (qp.cc:337-342)
         }
       }
-      if (g == 0) ysm[16 + j] = -r_pe;
+      if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < NY; ++q) ysm[YN + 16 * q + j] = -r_pe[q];
+      }
       lds_fence();
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const double rv = tmp[16 * c + g + 4 * t];
-          if (j == kRC) U[c * NB + NT][t] = rv;
+          if (j == kRC) U[c * NB + LT][t] = rv;
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {  // y diagonal tile = [0, -r_pe; -r_pe^T, 0]
+      for (int t = 0; t < 4; ++t) {  // last y diagonal tile = [0, -r_pe; -r_pe^T, 0]
         double v = 0.0;
-        if (j == kRC) v = ysm[16 + g + 4 * t];
-        if (g + 4 * t == kRC) v = -r_pe;
-        U[NT * NB + NT][t] = v;
+        if (j == kRC) v = ysm[YN + 16 * (NY - 1) + g + 4 * t];
+        if (g + 4 * t == kRC) v = -r_pe[NY - 1];
+        U[LT * NB + LT][t] = v;
+        if constexpr (NY == 2) {     // the full y tile in front of it: its right-hand side rides in column kRC of tile (NT, LT)
+          U[NT * NB + NT][t] = 0.0;
+          U[NT * NB + LT][t] = (j == kRC) ? ysm[YN + g + 4 * t] : 0.0;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!block_eliminate<NT, SW>(U, k, g, j)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+      if (!block_eliminate<NT, SW, NY>(U, k, g, j)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
       double xb[NB];
-      back_substitute<NT>(U, k, j, xb);      // xb[c] = dx (permuted), xb[NT] = -dy
-      double dyv = 0.0, dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
+      back_substitute<NT, NY>(U, k, j, xb);  // xb[c] = dx (permuted), xb[NT + q] = -dy
+      double dyv[NY], dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
+#pragma unroll
+      for (int q = 0; q < NY; ++q) dyv[q] = 0.0;
       // From a solution xb to the direction: dy, dx (natural order in LDS), ds, dz, the step lengths (qp.cc:359-363, 485-507).
       auto finish_direction = [&](double mu_s, double tau) -> bool {
-        dyv = (j < k) ? -xb[NT] : 0.0;
-        bool finite = fabs(dyv) < INFINITY;
+        bool finite = true;
+#pragma unroll
+        for (int q = 0; q < NY; ++q) {
+          dyv[q] = (16 * q + j < k) ? -xb[NT + q] : 0.0;
+          finite = finite && (fabs(dyv[q]) < INFINITY);
+        }
 #pragma unroll
         for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
         if (g == 0) {
@@ -1824,13 +1867,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         return true;
       };
       if (guess_pass) {                      // qp.cc:455-460: x, y <- the equality-constrained solution
-        bool finite = (j < k) ? (fabs(xb[NT]) < INFINITY) : true;
+        bool finite = true;
+#pragma unroll
+        for (int q = 0; q < NY; ++q) finite = finite && ((16 * q + j < k) ? (fabs(xb[NT + q]) < INFINITY) : true);
 #pragma unroll
         for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
         if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
 #pragma unroll
         for (int c = 0; c < NT; ++c) xv[c] = xb[c];
-        yv = (j < k) ? -xb[NT] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NY; ++q) yv[q] = (16 * q + j < k) ? -xb[NT + q] : 0.0;
         guess_pass = false;
         clamp_and_init_slacks();
         continue;
@@ -1873,16 +1919,18 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           ldv<NT, QPL>(rhoS, j, rr);
 #pragma unroll
           for (int c = 0; c < NT; ++c) rb[c] = -(r_d[c] + rr[c]);
-          rb[NT] = (j < k) ? -r_pe : 0.0;
+#pragma unroll
+          for (int q = 0; q < NY; ++q) rb[NT + q] = -r_pe[q];  // zero on lanes beyond k
         }
-        solve_second_rhs<NT>(U, k, g, j, rb, diagS, xp, ysm + 16, xb);
+        solve_second_rhs<NT, NY>(U, k, g, j, rb, diagS, xp, ysm + YN, xb);
         if (!finish_direction(mu_pc, 0.995)) { st = MO_STATUS_NONFINITE; break; }
         ip_mu = mu_pc;
       }
       // x,s += alpha_p (dx,ds) ; y,z += alpha_d (dy,dz), qp.cc:196-199
 #pragma unroll
       for (int c = 0; c < NT; ++c) xv[c] = fma(xb[c], ap, xv[c]);
-      yv = fma(dyv, ad, yv);
+#pragma unroll
+      for (int q = 0; q < NY; ++q) yv[q] = fma(dyv[q], ad, yv[q]);
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci) { cs[ci] = fma(dsv[ci], ap, cs[ci]); cz[ci] = fma(dzv[ci], ad, cz[ci]); }
       mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
@@ -1894,7 +1942,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
           for (int ci = 0; ci < MC; ++ci)
             if (lane + 64 * ci < m) { dp[nn + lane + 64 * ci] = dsv[ci]; dp[nn + m + k + lane + 64 * ci] = dzv[ci]; }
-          if (g == 0 && j < k) dp[nn + m + j] = dyv;
+#pragma unroll
+          for (int q = 0; q < NY; ++q)
+            if (g == 0 && 16 * q + j < k) dp[nn + m + 16 * q + j] = dyv[q];
         }
         if (a.ip_out && lane == 0) {
           double* ip = (double*)a.ip_out + p * MO_IP_RECORD;
@@ -1909,13 +1959,21 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     if (!residual_mode) {  // the state is an input only there
       if (g == 0) {
         stv_n<NT, QPL>(vp, j, nn, xv);
-        if (j < k) vp[nn + m + j] = yv;
+#pragma unroll
+        for (int q = 0; q < NY; ++q)
+          if (16 * q + j < k) vp[nn + m + 16 * q + j] = yv[q];
       }
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci)
         if (lane + 64 * ci < m) { vp[nn + lane + 64 * ci] = cs[ci]; vp[nn + m + k + lane + 64 * ci] = cz[ci]; }
     }
-    const double ymin = row_min((j < k) ? yv : INFINITY), yabs = -row_min((j < k) ? -fabs(yv) : INFINITY);
+    double ymin_l = INFINITY, yabs_l = INFINITY;
+#pragma unroll
+    for (int q = 0; q < NY; ++q) {
+      ymin_l = fmin(ymin_l, (16 * q + j < k) ? yv[q] : INFINITY);
+      yabs_l = fmin(yabs_l, (16 * q + j < k) ? -fabs(yv[q]) : INFINITY);
+    }
+    const double ymin = row_min(ymin_l), yabs = -row_min(yabs_l);
     if (lane == 0) {
       if (a.termination) a.termination[p] = term;
       if (a.num_iterations) a.num_iterations[p] = it;
@@ -1960,7 +2018,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP && a.mode != MODE_RESIDUAL) return false;
   if (a.mode == MODE_RESIDUAL && !a.r_out) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
-  if (a.k > 15 || a.m < 0) return false;
+  if (a.k > 31 || a.m < 0) return false;  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31
   // two constraint slots per lane (m <= 128): the step kernel on every tile grid, Solve / Iterate on the 32 / 64 grids
   if (a.m > ((a.mode == MODE_STEP || a.n <= 64) ? 128 : 64)) return false;
   if (!a.ticket || !a.vars) return false;
@@ -2004,6 +2062,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
 #if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)  // (the diagnostic builds of tools/phase_timer*.hip link this file alone)
+  if (a.mode != MODE_LINEARIZE && a.k > 15) return launch_fused_ny2(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && fused_needs_gather(a)) return launch_fused_gather(a, num_cus, stream);
 #endif
   if (a.mode == MODE_LINEARIZE) {

@@ -1,0 +1,46 @@
+// kkt_fused_ny2.hip -- the fused fp64 kernels (kkt_fused.hip) instantiated with TWO y tiles (NY = 2): 16 <= k <= 31 equality constraints.
+// The first y tile is a full 16-pivot tile of the Schur complement, the second holds the remaining k - 16 rows and, as in the one-tile
+// kernels, carries the right-hand side in index 15.  A translation unit of its own so that the instantiations compile beside the others.
+// Waves per SIMD follow the register budget of the (NT + 2)(NT + 3) / 2 live tiles: 3 on the 32 grid, 2 on the 64 grid, 1 beyond.
+#define MO_FUSED_IMPL_ONLY
+#include "kkt_fused.hip"
+
+namespace mo {
+
+hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream) {  // the work counter has been zeroed by launch_fused
+  const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
+  const int grid_tile = a.n > 96 ? 8 : a.n > 64 ? 6 : a.n > 32 ? 4 : 2;
+  const int wps = grid_tile == 2 ? 3 : grid_tile == 4 ? 2 : 1;
+  // J-level input: 16-byte pieces of a packed row-major J, or the per-lane gather stream for every other layout (odd n included)
+  const bool gather = a.J && (fused_needs_gather(a) || (a.n & 1));
+  long long grid = num_cus;
+  const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+  if (grid > need) grid = need;
+  if (grid < 1) grid = 1;
+  const dim3 gd((unsigned)grid), bd(256 * wps);
+#define MO_NY2(KERNEL, NT_, WPS_, MC_)                                                                                       \
+  do {                                                                                                                       \
+    if (!a.J) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, true, MC_, JMODE_VECTOR, 2>), gd, bd, 0, stream, a);                  \
+    else if (gather) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, 1, JMODE_GATHER, 2>), gd, bd, 0, stream, a);            \
+    else hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, MC_, JMODE_VECTOR, 2>), gd, bd, 0, stream, a);                      \
+  } while (0)
+  if (solve) {  // two constraint slots per lane on the 32 / 64 grids only (fused_supported)
+    switch (grid_tile) {
+      case 2: MO_NY2(kkt_fused_solve_kernel, 2, 3, 2); break;
+      case 4: MO_NY2(kkt_fused_solve_kernel, 4, 2, 2); break;
+      case 6: MO_NY2(kkt_fused_solve_kernel, 6, 1, 1); break;
+      default: MO_NY2(kkt_fused_solve_kernel, 8, 1, 1); break;
+    }
+  } else {
+    switch (grid_tile) {
+      case 2: MO_NY2(kkt_fused_f64_kernel, 2, 3, 2); break;
+      case 4: MO_NY2(kkt_fused_f64_kernel, 4, 2, 2); break;
+      case 6: MO_NY2(kkt_fused_f64_kernel, 6, 1, 2); break;
+      default: MO_NY2(kkt_fused_f64_kernel, 8, 1, 2); break;
+    }
+  }
+#undef MO_NY2
+  return hipGetLastError();
+}
+
+}  // namespace mo

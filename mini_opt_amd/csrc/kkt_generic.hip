@@ -42,6 +42,10 @@
 namespace mo {
 namespace {
 
+// Every stage is inlined into its kernel: with R = 9 / 12 hipcc otherwise keeps assemble_and_factor (two call sites in MODE_SOLVE) as a real
+// function, and the kernel that called it returned alpha_dual = 1 for every problem -- the records a caller reads after the call were lost.
+#define MO_INLINE __attribute__((always_inline))
+
 #ifdef MO_GENERIC_STAMPS
 __device__ unsigned long long g_nd_stamps[8];   // diagnostic build only: where newton_direction spends its time
 #define MO_NDSTAMP(i)                                                              \
@@ -143,7 +147,7 @@ template <typename T> __device__ inline T wave_min(T v) {
 
 // H <- 0 ; H.lower(n x n) <- G.lower ; H[n.., 0..n) <- A_eq ; cvec <- c ; beq <- b_eq      (qp.cc:47, 289-292)
 template <typename T>
-__device__ void load_qp(const Ws<T>& w, int n, int k, const T* G, int G_ld, const T* c, const T* A, int A_ld,
+__device__ MO_INLINE void load_qp(const Ws<T>& w, int n, int k, const T* G, int G_ld, const T* c, const T* A, int A_ld,
                         const T* b, int tid) {
   const int P = n + k;
   for (int idx = tid; idx < P * w.ldh; idx += kThreads) w.H[idx] = (T)0;
@@ -192,7 +196,7 @@ __device__ inline void jtj_tile_rows_impl(const Ws<T>& w, int n, int rows, int t
 // H.lower(n x n) += J^T J, cvec = J^T r, diag += lambda; returns 0.5|r|^2 in w.red[8]   (residual.hpp:206-225,
 // nonlinear.cc:182-189).  H must be zero in its n x n block and cvec is overwritten.
 template <typename T, int TG, int R>
-__device__ void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r,
+__device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r,
                                T lambda, int tid) {
   for (int i = tid; i < n; i += kThreads) w.cvec[i] = (T)0;
   if (tid == 0) w.red[8] = (T)0;
@@ -236,7 +240,7 @@ __device__ void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J
 
 // EvaluateKKTConditions, qp.cc:391-420.  H must hold G (lower) and A_eq (no Sigma yet).
 template <typename T>
-__device__ void eval_kkt(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+__device__ MO_INLINE void eval_kkt(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
   const T* x = w.vars; const T* s = w.vars + n; const T* y = w.vars + n + m; const T* z = w.vars + n + m + k;
   T* r_d = w.res; T* r_comp = w.res + n; T* r_pe = w.res + n + m; T* r_pi = w.res + n + m + k;
   for (int i = tid; i < n; i += kThreads) {
@@ -271,7 +275,7 @@ __device__ void eval_kkt(const Ws<T>& w, int n, int k, int m, bool include_ineq,
 
 // ComputeErrors, qp.cc:423-437 -> w.red[0..3]
 template <typename T>
-__device__ void compute_errors(const Ws<T>& w, int n, int k, int m, T mu, int tid) {
+__device__ MO_INLINE void compute_errors(const Ws<T>& w, int n, int k, int m, T mu, int tid) {
   if (tid < 64) {
     const T* r_d = w.res; const T* r_comp = w.res + n; const T* r_pe = w.res + n + m; const T* r_pi = w.res + n + m + k;
     T a = 0, b = 0, c1 = 0, c2 = 0, d = 0;
@@ -296,7 +300,7 @@ __device__ void compute_errors(const Ws<T>& w, int n, int k, int m, T mu, int ti
 
 // ComputeMu, qp.cc:509-516 -> w.red[4]
 template <typename T>
-__device__ void compute_mu(const Ws<T>& w, int n, int k, int m, int tid) {
+__device__ MO_INLINE void compute_mu(const Ws<T>& w, int n, int k, int m, int tid) {
   if (tid < 64) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
     T a = 0;
@@ -315,7 +319,7 @@ __device__ void compute_mu(const Ws<T>& w, int n, int k, int m, int tid) {
 // the zeros and stay.  The LDS-resident loop this replaces read two operands and wrote one result through LDS for every FMA.
 // Afterwards H holds W = L D below the diagonal and invd = 1 / D, as the triangular solves expect.
 template <typename T, int TG, int R>
-__device__ int factor_in_registers(const Ws<T>& w, int P, int tid) {
+__device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
   const int ti = tid & (TG - 1), tj = tid / TG;
   T h[R * (R + 1) / 2];
 #pragma unroll
@@ -391,7 +395,7 @@ __device__ int factor_in_registers(const Ws<T>& w, int P, int tid) {
 
 // Reduced-KKT assembly (Sigma on the diagonal, qp.cc:293-298) + LDL^T.  Returns MO_STATUS_*.
 template <typename T, int TG, int R>
-__device__ int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+__device__ MO_INLINE int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
   const int P = n + k;
   if (include_ineq) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
@@ -413,7 +417,7 @@ __device__ int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool inc
 
 // Solve (L D L^T) sol = rhs in place, wave 0 only; H holds W = L D below the diagonal, invd = 1/D.
 template <typename T>
-__device__ void wave_solve(const Ws<T>& w, int P, int lane) {
+__device__ MO_INLINE void wave_solve(const Ws<T>& w, int P, int lane) {
   const int r0 = lane, r1 = lane + 64, r2 = lane + 128;
   T b0 = r0 < P ? w.rhs[r0] : (T)0, b1 = r1 < P ? w.rhs[r1] : (T)0, b2 = r2 < P ? w.rhs[r2] : (T)0;
   for (int kk = 0; kk < P; ++kk) {  // forward: t = L^-1 b
@@ -439,7 +443,7 @@ __device__ void wave_solve(const Ws<T>& w, int P, int lane) {
 
 // SolveForUpdate (qp.cc:318-364) / SolveForUpdateNoInequalities (qp.cc:366-386) with the factorisation in H.
 template <typename T>
-__device__ void solve_for_update(const Ws<T>& w, int n, int k, int m, T mu, bool include_ineq, int tid) {
+__device__ MO_INLINE void solve_for_update(const Ws<T>& w, int n, int k, int m, T mu, bool include_ineq, int tid) {
   const int P = n + k;
   const T* s = w.vars + n; const T* z = w.vars + n + m + k;
   const T* r_d = w.res; const T* r_comp = w.res + n; const T* r_pe = w.res + n + m; const T* r_pi = w.res + n + m + k;
@@ -478,7 +482,7 @@ __device__ void solve_for_update(const Ws<T>& w, int n, int k, int m, T mu, bool
 
 // ComputeAlpha, qp.cc:485-507 -> w.red[5] (primal), w.red[6] (dual)
 template <typename T>
-__device__ void compute_alpha(const Ws<T>& w, int n, int k, int m, T tau, int tid) {
+__device__ MO_INLINE void compute_alpha(const Ws<T>& w, int n, int k, int m, T tau, int tid) {
   if (tid < 64) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
     const T* ds = w.delta + n; const T* dz = w.delta + n + m + k;
@@ -495,7 +499,7 @@ __device__ void compute_alpha(const Ws<T>& w, int n, int k, int m, T tau, int ti
 
 // ComputePredictorCorrectorMuAffine, qp.cc:519-537 -> w.red[7]
 template <typename T>
-__device__ void compute_mu_affine(const Ws<T>& w, int n, int k, int m, T mu, T ap, T ad, int tid) {
+__device__ MO_INLINE void compute_mu_affine(const Ws<T>& w, int n, int k, int m, T mu, T ap, T ad, int tid) {
   if (tid < 64) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
     const T* ds = w.daff + n; const T* dz = w.daff + n + m + k;
@@ -516,7 +520,7 @@ __device__ void compute_mu_affine(const Ws<T>& w, int n, int k, int m, T mu, T a
 // Iterate's solve part (qp.cc:163-193), state update excluded.  Residual must be current, H = G + A.
 // ip[6] receives IPIterationOutputs.  Returns MO_STATUS_*.
 template <typename T, int TG, int R>
-__device__ int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input, int strategy, T tau, T* ip, int tid) {
+__device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input, int strategy, T tau, T* ip, int tid) {
   const int V = n + 2 * m + k;
   ip[0] = mu_input; ip[1] = 1; ip[2] = 1; ip[3] = nanT<T>(); ip[4] = nanT<T>(); ip[5] = nanT<T>();
   for (int i = tid; i < V; i += kThreads) w.daff[i] = (T)0;                        // delta_affine_.setZero(), :315
@@ -553,7 +557,7 @@ __device__ int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input,
 
 // x,s += alpha_p (dx,ds); y,z += alpha_d (dy,dz), qp.cc:196-199
 template <typename T>
-__device__ void update_state(const Ws<T>& w, int n, int k, int m, T ap, T ad, int tid) {
+__device__ MO_INLINE void update_state(const Ws<T>& w, int n, int k, int m, T ap, T ad, int tid) {
   const int V = n + 2 * m + k;
   for (int i = tid; i < V; i += kThreads) {
     const bool primal = i < n + m;

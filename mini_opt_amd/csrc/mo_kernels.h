@@ -72,6 +72,7 @@ const char* fused_name(const KernelArgs& a, int dtype);
 hipError_t launch_fused(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
 bool fused_needs_gather(const KernelArgs& a);  // J-level input in a layout only the per-lane gather stream takes
 hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t stream);  // kkt_fused_gather.hip
+hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream);     // kkt_fused_ny2.hip: 16 <= k <= 31
 
 
 // fused single-wave fp32 step kernel for n = 64 / 128 (J-level input), kkt_fused_f32.hip

@@ -20,7 +20,7 @@ def test_random_shapes_and_layouts(seed):
     rng = np.random.default_rng(seed)
     worst = 0.0
     for trial in range(40):
-        n = int(rng.integers(2, 129)); k = int(rng.integers(0, min(16, n))); m = int(rng.integers(0, 65)); m_r = int(rng.integers(1, 300)); B = 5
+        n = int(rng.integers(2, 129)); k = int(rng.integers(0, min(32, n + 1))); m = int(rng.integers(0, 65)); m_r = int(rng.integers(1, 300)); B = 5
         J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
         A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
         cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))

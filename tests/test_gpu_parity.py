@@ -708,20 +708,39 @@ def test_fused_vs_generic_random_shapes():
     """Forty random (n, k, m, m_r, input level, strategy) combinations through the fused kernels and through the generic kernel
     (MO_PLAN_FORCE_GENERIC): Newton step, Iterate (incl. predictor-corrector) and Solve must agree."""
     rng = np.random.default_rng(2026)
-    tried = 0
-    while tried < 40:
+    for _ in range(40):
         level = rng.choice(["J", "QP"])
         n = int(rng.integers(2, 65))                          # any n; odd n with J-level input takes the flat-group stream
-        k = int(rng.integers(0, min(16, n)))                  # up to 15 equalities
+        k = int(rng.integers(0, min(16, n)))                  # up to 15 equalities: one y tile
         m = int(rng.integers(0, 65))
         m_r = int(rng.integers(1, 160))                       # any row count: a partial last 4-row group included
-        V = n + 2 * m + k
-        tried += 1
+        _fused_vs_generic_case(rng, level, n, k, m, m_r)
+
+
+def test_fused_two_y_tiles_vs_generic_random_shapes():
+    """16 <= k <= 31 equality constraints: the fused kernels carry a second y tile (kkt_fused_ny2.hip).  Thirty random shapes on the
+    32 / 64 / 96 tile grids (m up to 128 where the one-tile kernels take it, odd n through the gather stream) against the generic kernel."""
+    rng = np.random.default_rng(3031)
+    for i in range(30):
+        level = rng.choice(["J", "QP"])
+        n = int(rng.integers(16, 65)) if i % 5 else int(rng.integers(65, 89))   # n + k <= 119: the LDS-resident generic kernel still holds it
+        k = int(rng.integers(16, min(32, n + 1)))
+        odd_stream = level == "J" and (n & 1)
+        m = int(rng.integers(0, 65 if (odd_stream or n > 64) else 129))
+        m_r = int(rng.integers(1, 160))
+        _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=True, kkt_tol=1e-6)
+
+
+def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-8):
         B = 9
         J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
         A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
         cv = rng.integers(0, n, (B, m)).astype(np.int32)
         ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+        if feasible:  # many equalities and up to 128 inequalities on few variables: make sure a strictly feasible point x0 exists,
+            x0 = rng.uniform(-0.5, 0.5, (B, n))                 # with margins small enough that some inequalities are active at the
+            b = -np.einsum("bik,bi->bk", A, x0)                 # optimum (none active: the predictor-corrector's full step lands on
+            cb = -ca * np.take_along_axis(x0, cv.astype(np.int64), axis=1) + rng.uniform(0.05, 0.5, (B, m))  # z + dz = 0 to rounding)
         x = rng.uniform(-0.1, 0.1, (B, n))
         sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
         vars_ = np.concatenate([x, sl, y, z], axis=1)
@@ -753,7 +772,7 @@ def test_fused_vs_generic_random_shapes():
             ip, st2 = s.Iterate(T(mu), strategy)
             assert torch.all(st2 == 0), tag
             after_iter = s.variables().cpu().numpy().copy()
-            out = s.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=10, barrier_strategy=strategy,
+            out = s.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=kkt_tol, max_iterations=10, barrier_strategy=strategy,
                                    initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
             assert torch.all(out.status == 0), tag
             got[force] = (delta.cpu().numpy(), alpha.cpu().numpy(), ip.cpu().numpy(), after_iter, s.variables().cpu().numpy().copy(),
@@ -784,7 +803,9 @@ def test_fused_vs_generic_random_shapes():
 
 
 @pytest.mark.parametrize("n,k,m,m_r,level", [(66, 4, 10, 72, "J"), (96, 8, 32, 192, "J"), (100, 14, 64, 200, "J"), (128, 10, 40, 256, "J"),
-                                             (81, 3, 20, 0, "QP"), (128, 14, 64, 0, "QP")])
+                                             (81, 3, 20, 0, "QP"), (128, 14, 64, 0, "QP"),
+                                             (96, 20, 32, 192, "J"), (128, 31, 64, 256, "J"), (128, 16, 30, 0, "QP"), (40, 16, 12, 80, "J"),
+                                             (64, 31, 64, 128, "J"), (127, 17, 20, 130, "J")])
 def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
     """The 96- and 128-variable tile grids of the fp64 fused kernels (sizes the LDS-resident generic kernel cannot hold at all once
     n + k > 141): Newton step against the oracle, and the whole Solve against the oracle's Solve."""
@@ -854,6 +875,47 @@ def test_large_fp64_plan_falls_back_cleanly():
     assert "LDS" in str(e.value)
     G, c, half = Q.linearize(prob)                                   # n = 128 alone still fits the generic kernel (k = m = 0 there)
     np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,k,m,dt", [(58, 21, 21, torch.float64), (60, 21, 21, torch.float64), (100, 8, 30, torch.float64), (100, 24, 30, torch.float64),
+                                      (128, 16, 40, torch.float32), (150, 20, 40, torch.float32)])
+def test_generic_solve_first_iteration_is_iterate(n, k, m, dt):
+    """One iteration of Solve from the caller's state (USER_PROVIDED, mu as given) is Iterate on that state: same kernel family, same
+    arithmetic, so the states afterwards are IDENTICAL and the iteration record carries Iterate's step lengths.  Covers every
+    factorisation variant of the generic kernel (P = n + k up to 80, up to 144, beyond); the P > 80 variants once returned alpha_dual = 1
+    from Solve for every problem (a stage hipcc had kept as a real function call), which only this comparison and the oracle caught."""
+    rng = np.random.default_rng(n + k)
+    B, m_r = 5, n + 30
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n)); sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    lam = 1e-2
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J, dt), r=T(r, dt), lam=lam, A_eq=T(A, dt), b_eq=T(b, dt), cons_var=T(cv, torch.int32),
+                       cons_a=T(ca, dt), cons_b=T(cb, dt))
+    for strategy in (Q.COMPLEMENTARITY, Q.PREDICTOR_CORRECTOR):
+        s = Q.QPInteriorPointSolver(prob, force_generic=True)
+        s.SetVariables(T(vars_, dt))
+        out = s.Solve(Q.Params(initial_mu=0.05, sigma=0.1, max_iterations=1, barrier_strategy=strategy, initial_guess_method=Q.USER_PROVIDED,
+                               initialize_mu_with_complementarity=False))
+        assert torch.all(out.status == 0)
+        after_solve = s.variables().clone()
+        rec = out.iterations[:, 0].cpu().numpy()
+        s.SetVariables(T(vars_, dt))
+        ip, st = s.Iterate(T(np.full(B, 0.05), dt), strategy)
+        assert torch.all(st == 0)
+        assert torch.equal(after_solve, s.variables()), (n, k, strategy)
+        np.testing.assert_array_equal(rec[:, 8:14], ip.cpu().numpy())
+        assert np.any(rec[:, 10] < 1.0)                                        # the case has a cut dual step to report
+        if dt == torch.float64:                                                # and the oracle's Iterate agrees
+            G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); c = np.einsum("bqi,bq->bi", J, r)
+            for p in range(2):
+                o = orc.Solver(orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p]))
+                o.variables[:] = vars_[p]
+                ost, oip = o.iterate(0.05, strategy)
+                assert ost == 0
+                np.testing.assert_allclose([rec[p, 9], rec[p, 10]], [oip.alpha_primal, oip.alpha_dual], rtol=1e-7)
 
 
 @pytest.mark.parametrize("n,k,m,m_r,level", [(64, 8, 128, 128, "J"), (32, 4, 65, 64, "J"), (64, 0, 100, 0, "QP"), (20, 3, 128, 0, "QP"),
@@ -1064,7 +1126,7 @@ def _layouts_of(J):
 
 
 @pytest.mark.parametrize("n,k,m,m_r", [(64, 8, 32, 128), (32, 4, 16, 64), (40, 3, 10, 50), (63, 8, 32, 131), (96, 8, 40, 192), (101, 5, 20, 203),
-                                       (128, 10, 40, 256), (6, 2, 4, 9)])
+                                       (128, 10, 40, 256), (6, 2, 4, 9), (48, 20, 10, 70), (33, 31, 16, 41), (100, 16, 30, 150)])
 def test_fused_kernels_take_every_layout_of_J(n, k, m, m_r):
     """Column-major J, a leading dimension beyond n, rows that are only 8-byte aligned, odd n beyond 64: all of them run on the fused
     kernels (the gather stream, kkt_fused_gather.hip) and give the packed layout's results -- step against the oracle, Iterate, Solve and

@@ -27,8 +27,12 @@ def main():
     ap.add_argument("--no-records", action="store_true", help="Solve without the per-iteration records")
     ap.add_argument("--layout", default="packed", choices=["packed", "col", "rowld"],
                     help="layout of J: packed row-major (16-byte stream), column-major or row-major with ld = n + 2 (gather stream)")
+    ap.add_argument("--shape", default="", help="n,k,m,m_r in fp64 instead of a named config (e.g. 64,24,32,128: the two-y-tile kernels)")
     args = ap.parse_args()
     d = synth.CONFIGS[args.config]
+    if args.shape:
+        n_, k_, m_, mr_ = (int(v) for v in args.shape.split(","))
+        d = dict(n=n_, k=k_, m=m_, m_r=mr_, dtype="f64", batch=65536)
     dev = torch.device("cuda:0")
     dt = torch.float64 if d["dtype"] == "f64" else torch.float32
     batch = args.batch or d["batch"]
