@@ -140,6 +140,8 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** plan);
 int mo_plan_destroy(mo_plan* plan);
 /* Name of the kernel variant mo_newton_step will launch for this plan and problem layout ("generic", "fused_n64", ...). */
 const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob);
+/* The same for mo_qp_solve / mo_iterate / mo_kkt_residual ("generic", "fused_solve_mfma_f64_n64", "fused_solve_mfma_f32_n128", ...). */
+const char* mo_plan_solve_kernel(const mo_plan* plan, const mo_problem* prob);
 
 /* Replaces LinearizeAndFillQP's cost part (nonlinear.cc:182-189; Residual::Model::UpdateHessian, residual.hpp:186-226):
  * G_out (n x n col-major, leading dim G_ld; lower triangle written, strict upper written as 0) = J^T J + lambda I,

@@ -464,15 +464,663 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// QPInteriorPointSolver::Solve (qp.cc:100-151), one Iterate (qp.cc:153-201) and EvaluateKKTConditions + ComputeErrors
+// (qp.cc:391-437) in fp32, one wavefront per QP -- the fp32 sibling of kkt_fused_solve_kernel (kkt_fused.hip): every pass
+// rebuilds the G tiles (first pass: J through the LDS-DMA ring; later passes: the parked tiles), evaluates the KKT residual
+// as tile products K [x; -y] in registers (qp.cc:404-419), and solves for the DIRECTION with the residual as right-hand
+// side (qp.cc:255-268, 337-363).  All three BarrierStrategy values; PREDICTOR_CORRECTOR pushes its second right-hand side
+// through the factors of the predictor solve.  Tile layout and variable permutation as in the step kernel above (row 4g + t,
+// position 16c + i <-> variable 64(c>>2) + 4i + (c&3)); the right-hand side rides in column 0 of tile column NR = NT + 1.
+template <int NT> struct SolveCfg32 {
+  static constexpr int N = 16 * NT;
+  static constexpr int NH = NT / 4;
+  static constexpr int DPS = NH + 1;
+  static constexpr int SLOT = NH * 1024 + 64;
+  static constexpr int D = 4;
+  static constexpr int VEC = (6 * N + 32) * 4;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32]
+  static constexpr int LDS = D * SLOT + VEC;
+};
+
+__device__ inline float wave_sum_f32(float v) { return cross_row_sum_f32(row_sum_f32(v)); }
+__device__ inline int natvar32(int c, int i) { return 64 * (c >> 2) + 4 * i + (c & 3); }  // variable at tile position 16c + i
+
+// A second right-hand side through the factors the elimination left in the tiles (diagonal tiles: -T^-1, row panels: their
+// forward-eliminated values).  Vectors are V16 (value at lane j, replicated over g); rb[] is consumed; the forward-eliminated
+// blocks are parked in rbuf_x / rbuf_y for the substitution.  xb[c] = solution at permuted position 16c + j, xb[NT] = the y block.
+template <int NT>
+__device__ inline void solve_second_rhs_f32(const f4 (&U)[(NT + 2) * (NT + 2)], int g, int j, float (&rb)[NT + 1], float* hop, float* rbuf_x,
+                                            float* rbuf_y, float (&xb)[NT + 1]) {
+  constexpr int NB = NT + 2;
+#pragma unroll
+  for (int pa = 0; pa <= NT; ++pa) {  // forward: r_b += U_ab^T (-T_a^-1 r_a), b > a
+    if (g == 0) { hop[j] = rb[pa]; (pa < NT ? rbuf_x + 16 * pa : rbuf_y)[j] = rb[pa]; }
+    lds_fence32();
+    if (pa < NT) {
+      float q = 0.0f;
+      {
+        const f4 h4 = *(const f4*)(hop + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q = fmaf(U[pa * NB + pa][t], h4[t], q);
+      }
+      const float w = cross_row_sum_f32(q);  // (-T_a^-1 r_a)(j)
+      lds_fence32();                         // hop has been read
+      if (g == 0) hop[j] = w;
+      lds_fence32();
+      const f4 wr = *(const f4*)(hop + 4 * g);
+#pragma unroll
+      for (int pb = pa + 1; pb <= NT; ++pb) {
+        float q2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q2 = fmaf(U[pa * NB + pb][t], wr[t], q2);
+        rb[pb] += cross_row_sum_f32(q2);
+      }
+      lds_fence32();                         // hop has been read before the next block overwrites it
+    }
+  }
+#pragma unroll
+  for (int pa = NT; pa >= 0; --pa) {  // backward
+    const float* rsrc = pa < NT ? rbuf_x + 16 * pa : rbuf_y;
+    const f4 r4 = *(const f4*)(rsrc + 4 * g);
+    float vt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float pt = 0.0f;
+#pragma unroll
+      for (int pb = pa + 1; pb <= NT; ++pb) pt = fmaf(U[pa * NB + pb][t], xb[pb], pt);
+      if (pa < NT) pt = row_sum_f32(pt);
+      vt[t] = r4[t] - pt;
+    }
+    float q = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q = fmaf(U[pa * NB + pa][t], vt[t], q);
+    xb[pa] = -cross_row_sum_f32(q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NT, int WPS>
+__global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(const KernelArgs a) {
+  using C = SolveCfg32<NT>;
+  constexpr int N = C::N, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
+  constexpr int NB = NT + 2, NR = NT + 1;          // tile columns: x blocks 0..NT-1, y block NT, right-hand side NR
+  constexpr int WAVES = 4 * WPS;
+
+  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* const smem = smem_all + wave * C::LDS;
+  float* const xs = reinterpret_cast<float*>(smem + D * SLOT);  // x, natural order
+  float* const xp = xs + N;                                      // x, position order
+  float* const azS = xp + N;                                     // sum a z per variable, natural order
+  float* const diagS = azS + N;                                  // barrier diagonal per variable
+  float* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
+  float* const tmp = rhoS + N;                                   // layout-conversion scratch
+  float* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
+  const unsigned ring_base = (unsigned)(uintptr_t)smem;
+
+  const int k = a.k, m = a.m, m_r = a.m_r;
+  const int nsteps = m_r >> 2;
+  const float inv_m = m > 0 ? 1.0f / (float)m : 0.0f;
+  const mo_solve_params& sp = a.sp;
+  const bool qpl = a.J == nullptr;  // wave-uniform: QP-level input (G, c given)
+
+  const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  auto chunk_for = [&](long long observed) -> int {
+    const long long c = (a.batch - observed) >> chunk_shift;
+    return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
+  };
+  auto take_ticket = [&](int chunk) -> unsigned long long {
+    unsigned long long t = 0;
+    if (lane_id32() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    return t;
+  };
+  auto uniform64 = [](unsigned long long v) -> long long {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  int chunk = chunk_for(0);
+  long long p = uniform64(take_ticket(chunk));
+  long long chunk_end = p + chunk;
+
+  while (p < a.batch) {
+    const bool last_of_chunk = p + 1 >= chunk_end;
+    int next_chunk = 0;
+    unsigned long long next_ticket = 0;
+    if (last_of_chunk) {
+      next_chunk = chunk_for(p);
+      next_ticket = take_ticket(next_chunk);
+    }
+    if (a.skip && a.skip[p * a.skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
+      if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+      continue;
+    }
+    const int lane = lane_id32();
+    const int g = lane >> 4, j = lane & 15;
+
+    float* vp = (float*)a.vars + p * a.vars_stride;
+    const float lam_in = a.lambda_vec ? ((const float*)a.lambda_vec)[p * a.lambda_vec_stride] : (float)a.lambda;
+    const float lam = (!qpl && lam_in > 0.0f) ? lam_in : 0.0f;  // a given G already carries the LM damping
+
+    // ---- constants of the problem
+    int cvar = 0; float ca = 1.0f, cb = 0.0f;
+    if (lane < m) {
+      cvar = a.cons_var[p * a.cons_stride + lane];
+      ca = ((const float*)a.cons_a)[p * a.cons_stride + lane];
+      cb = ((const float*)a.cons_b)[p * a.cons_stride + lane];
+    }
+    float b_col = 0.0f;
+    if (j < k) b_col = ((const float*)a.b + p * a.b_stride)[j];
+    const float* const Ap = k > 0 ? (const float*)a.A + p * a.A_stride : nullptr;
+
+    // ---- state: x in the V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
+    float xv[NT], yv = 0.0f, cs = 1.0f, cz = 1.0f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) xv[c] = 0.0f;
+    const bool residual_mode = a.mode == MODE_RESIDUAL;
+    const bool iterate_mode = a.mode == MODE_ITERATE || residual_mode;
+    if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+#pragma unroll
+      for (int c = 0; c < NT; ++c) xv[c] = vp[natvar32(c, j)];
+      if (j < k) yv = vp[N + m + j];
+      if (lane < m) { cs = vp[N + lane]; cz = vp[N + m + k + lane]; }
+    }
+    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= N)));
+    if (bad_index) cvar = 0;
+
+    int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
+    int term = MO_MAX_ITERATIONS, it = 0;
+    float mu = iterate_mode ? (a.mu ? ((const float*)a.mu)[p * a.mu_stride] : 0.0f) : (float)sp.initial_mu;
+    bool guess_pass = !iterate_mode && sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
+    float* iter_out = a.iterations ? (float*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
+
+    // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
+    auto clamp_and_init_slacks = [&]() {
+      if (g == 0) stv32<NT>(xs, j, xv);
+      lds_fence32();
+      for (int c = 0; c < m; ++c) {  // wave-uniform loop; one constraint at a time keeps the reference's order
+        if (lane == c) {
+          const float x0 = xs[cvar];
+          float x1;
+          if (ca < 0.0f) { const float lim = cb / -ca; x1 = x0 < lim ? x0 : lim; }  // ClampX, qp.hpp:43-53
+          else { const float lim = -cb / ca; x1 = x0 > lim ? x0 : lim; }
+          xs[cvar] = x1;
+        }
+        lds_fence32();
+      }
+      ldv32<NT>(xs, j, xv);
+      float sz = 0.0f;
+      if (lane < m) {
+        const float sv = ca * xs[cvar] + cb;
+        cs = sv > 1.0e-9f ? sv : 1.0e-9f;
+        cz = 1.0f / cs;
+        sz = cs * cz;
+      }
+      if (sp.initialize_mu_with_complementarity) mu = wave_sum_f32(sz) * inv_m;  // qp.cc:115
+    };
+    if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+    if (!iterate_mode && sp.initial_guess_method == MO_GUESS_USER_PROVIDED && sp.initialize_mu_with_complementarity)
+      mu = wave_sum_f32(lane < m ? cs * cz : 0.0f) * inv_m;  // qp.cc:115 on the caller's state (0 without inequalities, qp.cc:509-516)
+
+    float n_rd2 = 0, n_rpe2 = 0, n_rc2 = 0, n_rc1 = 0, n_rpi2 = 0;
+    // ComputeErrors (qp.cc:423-437) as SQUARED norms (the decisions compare squares; square roots only for the records)
+    auto kkt_errors_sq = [&](float mu_e, float (&o)[4]) {
+      o[0] = n_rd2;
+      o[2] = k > 0 ? n_rpe2 : 0.0f;
+      if (m > 0) {
+        const float corrected = n_rc2 - 2 * (n_rc1 * mu_e) + (mu_e * mu_e) * (float)m;
+        o[1] = corrected > 0.0f ? corrected : 0.0f;
+        o[3] = n_rpi2;
+      } else { o[1] = 0.0f; o[3] = 0.0f; }
+    };
+    // G = J^T J + lambda I and c = J^T r do not change between the passes: the first pass parks its tiles in a per-problem scratch
+    // (plan-owned, a.G_out; lane-linear), later passes reload them instead of re-streaming J
+    constexpr int NTILES = NT * (NT + 1) / 2, TILE_SCRATCH = NTILES * 256 + NT * 64;
+    float* const Gt = (!qpl && a.G_out) ? (float*)a.G_out + (size_t)p * TILE_SCRATCH : nullptr;
+    bool tiles_cached = false;
+    float mu_used = mu;
+    float ip_alpha_p = 1.0f, ip_alpha_d = 1.0f;
+    const bool use_pc = (iterate_mode ? a.barrier_strategy : sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
+    const float nanf32 = __builtin_nanf("");
+    float ip_mu = mu, probe_p = nanf32, probe_d = nanf32, mu_aff = nanf32, mu_pc = 0.0f;
+
+    while (st == MO_STATUS_OK) {
+      const bool include_ineq = !guess_pass && !(residual_mode && (a.flags & MO_STEP_NO_INEQUALITIES));
+      const int lane = lane_id32(), g = lane >> 4, j = lane & 15;  // re-made opaque every pass (nothing lane-derived is kept across the factorisation)
+      // ---------------------------------------------------------------- part A: tiles, residual, norms
+      const bool stream_now = !qpl && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;
+      const char* jsrc = reinterpret_cast<const char*>((const float*)a.J + p * a.J_stride + (size_t)g * N + 4 * j);
+      const char* rsrc = reinterpret_cast<const char*>((const float*)a.r + p * a.r_stride);
+      auto issue = [&](int slot) {
+        const unsigned dst = ring_base + slot * SLOT;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) dma16_f32(jsrc + 256 * h, dst + h * 1024);
+        if (lane < 1) dma16_f32(rsrc, dst + NH * 1024);
+        jsrc += 4 * N * 4;
+        rsrc += 16;
+      };
+      if (stream_now) {
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+          if (u < nsteps) issue(u);
+      }
+      f4 U[NB * NB];
+#pragma unroll
+      for (int q = 0; q < NB * NB; ++q) U[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      // publish the state for the layout conversions below; zero the per-variable scatter arrays
+      if (g == 0) {
+        stv32<NT>(xs, j, xv);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
+      }
+      for (int i = lane; i < N; i += 64) { azS[i] = 0.0f; diagS[i] = 0.0f; rhoS[i] = 0.0f; }
+      float cvec[NT];
+      if (qpl) {  // only the lower triangle of G is read (qp.cc:289, 404)
+        const float* Gp = (const float*)a.G + p * a.G_stride;
+        const float* cp = (const float*)a.c + p * a.c_stride;
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+          for (int tb = ta; tb < NT; ++tb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int vr = natvar32(ta, 4 * g + t), vc = natvar32(tb, j);
+              const int hi = vr > vc ? vr : vc, lo = vr > vc ? vc : vr;
+              U[ta * NB + tb][t] = Gp[hi + (size_t)lo * a.G_ld];
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) cvec[c] = cp[natvar32(c, j)];
+      } else if (stream_now) {
+        const char* const lane_piece = smem + lane * 16;
+        const char* const r_elem = smem + NH * 1024 + 4 * g;
+        float cpart[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) cpart[c] = 0.0f;
+        for (int q0 = 0; q0 < nsteps; q0 += D) {
+#pragma unroll
+          for (int u = 0; u < D; ++u) {
+            const int q = q0 + u;
+            if (q < nsteps) {
+              const int younger = nsteps - 1 - q;  // groups that may stay in flight (DPS DMAs each)
+              if (younger >= D - 1) wait_vmcnt32<(D - 1) * DPS>();
+              else if (younger == 2) wait_vmcnt32<2 * DPS>();
+              else if (younger == 1) wait_vmcnt32<1 * DPS>();
+              else wait_vmcnt32<0>();
+              float ops[NT];
+#pragma unroll
+              for (int h = 0; h < NH; ++h) {
+                const f4 v = *(const f4*)(lane_piece + u * SLOT + h * 1024);
+                ops[4 * h] = v[0]; ops[4 * h + 1] = v[1]; ops[4 * h + 2] = v[2]; ops[4 * h + 3] = v[3];
+              }
+              const float rq = *(const float*)(r_elem + u * SLOT);
+              lds_fence32();  // the slot's bytes are in registers before the slot is handed back to the DMA engine
+              if (q + D < nsteps) issue(u);
+#pragma unroll
+              for (int ta = 0; ta < NT; ++ta) {
+                cpart[ta] = fmaf(ops[ta], rq, cpart[ta]);
+#pragma unroll
+                for (int tb = ta; tb < NT; ++tb)
+                  U[ta * NB + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+              }
+            }
+          }
+        }
+        wait_vmcnt32<0>();
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {  // G = J^T J + lambda I (nonlinear.cc:187-189): lambda is part of G in the residual too
+#pragma unroll
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == 4 * g + t) ? lam : 0.0f;
+          cvec[c] = cross_row_sum_f32(cpart[c]);
+        }
+        if (Gt) {  // park the tiles and c for the following passes
+          int ti = 0;
+#pragma unroll
+          for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+            for (int tb = ta; tb < NT; ++tb, ++ti) *(f4*)(Gt + ((size_t)ti * 64 + lane) * 4) = U[ta * NB + tb];
+          }
+#pragma unroll
+          for (int c = 0; c < NT; ++c) Gt[NTILES * 256 + c * 64 + lane] = cvec[c];
+          tiles_cached = true;
+        }
+      } else {  // reload what the first pass parked
+        int ti = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+          for (int tb = ta; tb < NT; ++tb, ++ti) U[ta * NB + tb] = *(const f4*)(Gt + ((size_t)ti * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) cvec[c] = Gt[NTILES * 256 + c * 64 + lane];
+      }
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {  // [A_eq^T] tile column
+#pragma unroll
+        for (int t = 0; t < 4; ++t) U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)natvar32(c, 4 * g + t) * a.A_ld] : 0.0f;
+      }
+      lds_fence32();
+      float r_pi = 0.0f, r_comp = 0.0f;
+      if (include_ineq && lane < m) {
+        atomicAdd(&azS[cvar], ca * cz);               // qp.cc:415
+        r_pi = ca * xs[cvar] + cb - cs;               // qp.cc:416
+        r_comp = cs * cz;                             // qp.cc:417
+      }
+      float r_d[NT], r_pe;
+      {
+        // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
+        // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
+        float acc1[NT + 1];
+#pragma unroll
+        for (int b = 0; b <= NT; ++b) acc1[b] = 0.0f;
+#pragma unroll
+        for (int ra = 0; ra < NT; ++ra) {
+          const f4 vR = *(const f4*)(xp + 16 * ra + 4 * g);  // x at the tile's rows 4g .. 4g + 3
+#pragma unroll
+          for (int b = ra; b <= NT; ++b) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc1[b] = fmaf(U[ra * NB + b][t], vR[t], acc1[b]);
+          }
+          f4 pt4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float pt = 0.0f;
+#pragma unroll
+            for (int b = ra + 1; b <= NT; ++b) pt = fmaf(U[ra * NB + b][t], b < NT ? xv[b < NT ? b : 0] : -yv, pt);  // yv is zero beyond k
+            pt4[t] = row_sum_f32(pt);
+          }
+          if (j == 0) *(f4*)(tmp + 16 * ra + 4 * g) = pt4;
+        }
+        lds_fence32();
+        {
+          float azv[NT];
+          ldv32<NT>(azS, j, azv);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum_f32(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
+        }
+        r_pe = (j < k) ? cross_row_sum_f32(acc1[NT]) + b_col : 0.0f;                                          // qp.cc:408
+        float t = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t = fmaf(r_d[c], r_d[c], t);
+        n_rd2 = readlane_f32(row_sum_f32(t), 0);
+        n_rpe2 = readlane_f32(row_sum_f32(r_pe * r_pe), 0);
+        n_rc2 = wave_sum_f32(r_comp * r_comp);
+        n_rc1 = wave_sum_f32(r_comp);
+        n_rpi2 = wave_sum_f32(r_pi * r_pi);
+      }
+      if (residual_mode) {  // r_ = [r_d | r_comp | r_pe | r_pi] (qp.cc:391-420) and the four norms of ComputeErrors (qp.cc:423-437)
+        float* ro = (float*)a.r_out + p * a.r_out_stride;
+        if (g == 0) {
+#pragma unroll
+          for (int c = 0; c < NT; ++c) ro[natvar32(c, j)] = r_d[c];
+          if (j < k) ro[N + m + j] = r_pe;
+        }
+        if (lane < m) { ro[N + lane] = r_comp; ro[N + m + k + lane] = r_pi; }
+        if (a.kkt_out) {
+          float kq[4];
+          kkt_errors_sq(mu, kq);
+          if (!include_ineq) { kq[1] = 0.0f; kq[3] = 0.0f; }
+          const float e0 = sqrtf(kq[0]), e1 = sqrtf(kq[1]), e2 = sqrtf(kq[2]), e3 = sqrtf(kq[3]);
+          if (lane == 0) { float* ko = (float*)a.kkt_out + 4 * p; ko[0] = e0; ko[1] = e1; ko[2] = e2; ko[3] = e3; }
+        }
+        break;
+      }
+      if (!guess_pass && !iterate_mode) {
+        // ---- the decision point of Solve (qp.cc:116-147)
+        if (it > 0) {
+          float kf[4];
+          kkt_errors_sq(mu_used, kf);                               // kkt_after of the previous iteration (squared), qp.cc:127
+          const float cur_mu = n_rc1 * inv_m;                       // ComputeMu, qp.cc:509-516
+          if (iter_out) {
+            const float r4 = sqrtf(kf[0]), r5 = sqrtf(kf[1]), r6 = sqrtf(kf[2]), r7 = sqrtf(kf[3]);
+            if (lane == 0) {
+              float* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
+              rec[4] = r4; rec[5] = r5; rec[6] = r6; rec[7] = r7;
+              rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
+              rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
+            }
+          }
+          float kmax2 = kf[0];                                      // KKTError::Max() squared
+          kmax2 = kf[1] > kmax2 ? kf[1] : kmax2; kmax2 = kf[2] > kmax2 ? kf[2] : kmax2; kmax2 = kf[3] > kmax2 ? kf[3] : kmax2;
+          const float tol = (float)sp.termination_kkt_tol;
+          if (kmax2 < tol * tol && cur_mu < (float)sp.termination_complementarity_tol) {  // qp.cc:132-137
+            term = MO_SATISFIED_KKT_TOL;
+            break;
+          }
+          if (kmax2 <= mu * mu || !sp.decrease_mu_only_on_small_error) {                   // qp.cc:140-146 (mu > 0)
+            if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= (float)sp.sigma;
+            else mu = (float)sp.sigma * cur_mu;
+          }
+        }
+        if (it >= sp.max_iterations) break;                          // MAX_ITERATIONS, qp.cc:149
+        if (iter_out) {                                              // kkt_prev is only ever recorded, qp.cc:118
+          float ki[4];
+          kkt_errors_sq(mu, ki);
+          const float r0 = sqrtf(ki[0]), r1 = sqrtf(ki[1]), r2 = sqrtf(ki[2]), r3 = sqrtf(ki[3]);
+          if (lane == 0) {
+            float* rec = iter_out + (size_t)it * MO_ITER_RECORD;
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
+          }
+        }
+      }
+      // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
+      const bool predictor_pass = use_pc && !guess_pass;
+      const float mu_step = m > 0 ? (predictor_pass ? 0.0f : mu) : 0.0f;  // qp.cc:165-187
+      float aff = 0.0f, cs_inv = 1.0f;  // aff = ds_aff dz_aff (qp.cc:341), set by the predictor
+      if (include_ineq) {
+        if (__any((lane < m) && !(cs > 0.0f))) { st = MO_STATUS_NONPOSITIVE_SLACK; break; }  // qp.cc:285
+        cs_inv = rcp_f32(cs);
+        if (lane < m) {
+          const float zs = cz * cs_inv;
+          atomicAdd(&diagS[cvar], ca * zs * ca);                                            // qp.cc:296
+          atomicAdd(&rhoS[cvar], ca * zs * r_pi + ca * (r_comp + aff - mu_step) * cs_inv);  // qp.cc:340-341
+        }
+      }
+      lds_fence32();
+      {
+        float dd[NT], rr[NT];
+        ldv32<NT>(diagS, j, dd);
+        ldv32<NT>(rhoS, j, rr);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == 4 * g + t) ? dd[c] : 0.0f;
+          if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[c]);          // -r_aug, position order (qp.cc:337-342)
+        }
+      }
+      if (g == 0) ysm[16 + j] = -r_pe;
+      lds_fence32();
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const f4 rv = *(const f4*)(tmp + 16 * c + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) U[c * NB + NR][t] = (j == 0) ? rv[t] : 0.0f;
+      }
+      {
+        const f4 rv = *(const f4*)(ysm + 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) U[NT * NB + NR][t] = (j == 0) ? rv[t] : 0.0f;  // -r_pe (zero beyond k)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bool ok = true;
+#pragma unroll
+      for (int pa = 0; pa <= NT; ++pa) {
+        ok = sweep_tile_f32(U[pa * NB + pa], pa < NT ? 16 : k, j) && ok;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pc = pa + 1; pc < NB; ++pc) {
+          const f4 negZ = mfma4_f32(U[pa * NB + pa], U[pa * NB + pc], f4{0.0f, 0.0f, 0.0f, 0.0f});  // (-T^-1) U_ac
+#pragma unroll
+          for (int pb = pa + 1; pb <= (pc < NT ? pc : NT); ++pb) U[pb * NB + pc] = mfma4_f32(U[pa * NB + pb], negZ, U[pb * NB + pc]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (!ok) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+      float xb[NT + 1];  // xb[c] = dx at position 16c + j, xb[NT] = -dy
+#pragma unroll
+      for (int pa = NT; pa >= 0; --pa) {
+        float vt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float pt = 0.0f;
+#pragma unroll
+          for (int pb = pa + 1; pb <= NT; ++pb) pt = fmaf(U[pa * NB + pb][t], xb[pb < NT + 1 ? pb : 0], pt);
+          pt = row_sum_f32(pt);
+          vt[t] = row_bcast_f32<0>(U[pa * NB + NR][t]) - pt;
+        }
+        float q = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q = fmaf(U[pa * NB + pa][t], vt[t], q);
+        xb[pa] = -cross_row_sum_f32(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float dyv = 0.0f, dsv = 0.0f, dzv = 0.0f, ap = 1.0f, ad = 1.0f;
+      // From a solution xb to the direction: dy, dx (natural order in LDS), ds, dz, the step lengths (qp.cc:359-363, 485-507).
+      auto finish_direction = [&](float mu_s, float tau) -> bool {
+        dyv = (j < k) ? -xb[NT] : 0.0f;
+        bool finite = fabsf(dyv) < INFINITY;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) finite = finite && (fabsf(xb[c]) < INFINITY);
+        if (g == 0) {
+          float dxn[NT];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) dxn[c] = xb[c];
+          stv32<NT>(tmp, j, dxn);  // dx, natural order
+        }
+        lds_fence32();
+        ap = 1.0f; ad = 1.0f; dsv = 0.0f; dzv = 0.0f;
+        if (lane < m) {
+          dsv = ca * tmp[cvar] + r_pi;                                         // qp.cc:361
+          dzv = -(cz * cs_inv) * dsv - cs_inv * (r_comp + aff - mu_s);         // qp.cc:362
+          if (cs + dsv <= 0.0f && fabsf(dsv) > 0.0f) ap = -tau * cs * rcp_f32(dsv);  // qp.cc:498-503
+          if (cz + dzv <= 0.0f && fabsf(dzv) > 0.0f) ad = -tau * cz * rcp_f32(dzv);
+          finite = finite && (fabsf(dsv) < INFINITY) && (fabsf(dzv) < INFINITY);
+        }
+        if (!__all(finite)) return false;
+        ap = cross_row_min_f32(row_min_f32(ap));
+        ad = cross_row_min_f32(row_min_f32(ad));
+        return true;
+      };
+      if (guess_pass) {                      // qp.cc:455-460: x, y <- the equality-constrained solution
+        bool finite = (j < k) ? (fabsf(xb[NT]) < INFINITY) : true;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) finite = finite && (fabsf(xb[c]) < INFINITY);
+        if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xv[c] = xb[c];
+        yv = (j < k) ? -xb[NT] : 0.0f;
+        guess_pass = false;
+        clamp_and_init_slacks();
+        continue;
+      }
+      if (!finish_direction(mu_step, predictor_pass ? 1.0f : 0.995f)) { st = MO_STATUS_NONFINITE; break; }  // tau: qp.cc:174, 192
+      ip_mu = mu;
+      if (predictor_pass) {
+        probe_p = ap; probe_d = ad;                                                    // alpha_probe, qp.cc:174
+        const float sdz = wave_sum_f32(lane < m ? cs * dzv : 0.0f), zds = wave_sum_f32(lane < m ? cz * dsv : 0.0f),
+                    dsdz = wave_sum_f32(lane < m ? dsv * dzv : 0.0f);
+        aff = dsv * dzv;                                                               // delta_affine_ (qp.cc:177)
+        float ma = mu;                                                                 // qp.cc:519-537
+        ma += ad * sdz * inv_m;
+        ma += ap * zds * inv_m;
+        ma += (ad * ap) * dsdz * inv_m;
+        mu_aff = ma > 0.0f ? ma : 0.0f;
+        const float ratio = mu_aff * rcp_f32(mu);
+        mu_pc = (ratio * ratio * ratio) * mu;                                          // qp.cc:182-183
+        // The corrector solve (qp.cc:187): same matrix, right-hand side with ds_aff dz_aff and sigma mu -- through the factors
+        for (int i = lane; i < N; i += 64) rhoS[i] = 0.0f;
+        lds_fence32();
+        if (lane < m) {
+          const float zs = cz * cs_inv;
+          atomicAdd(&rhoS[cvar], ca * zs * r_pi + ca * (r_comp + aff - mu_pc) * cs_inv);  // qp.cc:340-341
+        }
+        lds_fence32();
+        float rb[NT + 1];
+        {
+          float rr[NT];
+          ldv32<NT>(rhoS, j, rr);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) rb[c] = -(r_d[c] + rr[c]);
+          rb[NT] = -r_pe;  // zero beyond k
+        }
+        solve_second_rhs_f32<NT>(U, g, j, rb, diagS, xp, ysm + 16, xb);
+        if (!finish_direction(mu_pc, 0.995f)) { st = MO_STATUS_NONFINITE; break; }
+        ip_mu = mu_pc;
+      }
+      // x,s += alpha_p (dx,ds) ; y,z += alpha_d (dy,dz), qp.cc:196-199
+#pragma unroll
+      for (int c = 0; c < NT; ++c) xv[c] = fmaf(xb[c], ap, xv[c]);
+      yv = fmaf(dyv, ad, yv);
+      cs = fmaf(dsv, ap, cs); cz = fmaf(dzv, ad, cz);
+      mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
+      ++it;
+      if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
+        if (a.delta) {
+          float* dp = (float*)a.delta + p * a.delta_stride;
+          for (int i = lane; i < N; i += 64) dp[i] = tmp[i];  // dx, natural order
+          if (lane < m) { dp[N + lane] = dsv; dp[N + m + k + lane] = dzv; }
+          if (g == 0 && j < k) dp[N + m + j] = dyv;
+        }
+        if (a.ip_out && lane == 0) {
+          float* ip = (float*)a.ip_out + p * MO_IP_RECORD;
+          ip[0] = ip_mu; ip[1] = ap; ip[2] = ad;
+          ip[3] = probe_p; ip[4] = probe_d; ip[5] = mu_aff;
+        }
+        break;
+      }
+    }
+
+    // ---- outputs: state, termination, iteration count, Lagrange summary, status
+    if (!residual_mode) {
+      if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) vp[natvar32(c, j)] = xv[c];
+        if (j < k) vp[N + m + j] = yv;
+      }
+      if (lane < m) { vp[N + lane] = cs; vp[N + m + k + lane] = cz; }
+    }
+    const float ymin = row_min_f32((j < k) ? yv : INFINITY), yabs = -row_min_f32((j < k) ? -fabsf(yv) : INFINITY);
+    if (lane == 0) {
+      if (a.termination) a.termination[p] = term;
+      if (a.num_iterations) a.num_iterations[p] = it;
+      if (a.status) a.status[p] = st;
+      if (a.lagrange) {  // qp.cc:539-546
+        ((float*)a.lagrange)[2 * p] = k > 0 ? ymin : nanf32;
+        ((float*)a.lagrange)[2 * p + 1] = k > 0 ? yabs : nanf32;
+      }
+    }
+    wait_vmcnt32<0>();  // nothing of this problem's ring traffic is left in flight (a pass may leave through a break)
+    lds_fence32();
+    if (last_of_chunk) {
+      p = uniform64(next_ticket);
+      chunk_end = p + next_chunk;
+    } else {
+      ++p;
+    }
+  }
+}
+
 bool aligned16_f32(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
 bool fused_f32_supported(const KernelArgs& a, int dtype) {
-  if (dtype != MO_F32 || a.flags != 0 || a.mode != MODE_STEP) return false;
+  if (dtype != MO_F32) return false;
   if (a.n != 128 && a.n != 64) return false;
   if (a.k > 16 || a.m > 64 || a.m < 0) return false;
-  if (!a.ticket || !a.vars || !a.delta || !a.J) return false;
+  if (!a.ticket || !a.vars) return false;
+  if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {  // kkt_fused_f32_solve_kernel
+    if (a.mode == MODE_RESIDUAL ? ((a.flags & ~MO_STEP_NO_INEQUALITIES) != 0 || !a.r_out) : a.flags != 0) return false;
+    if (a.J) {
+      if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
+      if (!aligned16_f32(a.J) || (a.J_stride & 3) || !aligned16_f32(a.r) || (a.r_stride & 3)) return false;
+    } else if (!a.G || !a.c || a.G_ld < a.n) {
+      return false;
+    }
+    return true;
+  }
+  if (a.flags != 0 || a.mode != MODE_STEP) return false;
+  if (!a.delta || !a.J) return false;
   if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
   if (!aligned16_f32(a.J) || (a.J_stride & 3)) return false;
   if (!aligned16_f32(a.r) || (a.r_stride & 3)) return false;
@@ -480,7 +1128,11 @@ bool fused_f32_supported(const KernelArgs& a, int dtype) {
   return true;
 }
 
-const char* fused_f32_name(const KernelArgs& a) { return a.n == 128 ? "fused_mfma_f32_n128" : "fused_mfma_f32_n64"; }
+const char* fused_f32_name(const KernelArgs& a) {
+  if (a.mode == MODE_STEP) return a.n == 128 ? "fused_mfma_f32_n128" : "fused_mfma_f32_n64";
+  if (!a.J) return a.n == 128 ? "fused_solve_qp_f32_n128" : "fused_solve_qp_f32_n64";
+  return a.n == 128 ? "fused_solve_mfma_f32_n128" : "fused_solve_mfma_f32_n64";
+}
 
 hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t stream) {
   KernelArgs a = a_in;
@@ -489,6 +1141,16 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
+  if (a.mode != MODE_STEP) {  // Solve / Iterate / KKT residual: one wave per SIMD at n = 128 (216 tile registers + the state), two at n = 64
+    const int wps = a.n == 128 ? 1 : 2;
+    long long grid = num_cus;
+    const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+    return hipGetLastError();
+  }
   if (a.n == 128 && env_wps == 1) {
     constexpr int WPS = 1;
     long long grid = num_cus;

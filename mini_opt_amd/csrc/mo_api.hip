@@ -258,6 +258,21 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   }
 }
 
+const char* mo_plan_solve_kernel(const mo_plan* plan, const mo_problem* prob) {
+  if (!plan || !prob) return "invalid";
+  mo::KernelArgs a;
+  if (fill_problem(plan, prob, 1, true, true, &a) != MO_OK) return "invalid";
+  a.mode = mo::MODE_SOLVE;
+  a.vars = reinterpret_cast<void*>(16);  // layout query only
+  a.vars_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
+  a.ticket = plan->ticket;
+  switch (choose_kernel(plan, a)) {
+    case KERNEL_FUSED_F64: return mo::fused_name(a, plan->desc.dtype);
+    case KERNEL_FUSED_F32: return mo::fused_f32_name(a);
+    default: return "generic";
+  }
+}
+
 int mo_linearize(mo_plan* plan, const mo_problem* prob, int64_t batch, void* G_out, int64_t G_stride, int32_t G_ld,
                  void* c_out, int64_t c_stride, void* half_sq_out, void* stream) {
   g_err[0] = 0;
@@ -436,7 +451,7 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
   a.skip = skip; a.skip_stride = skip_stride;
   a.ticket = plan->ticket;
   const KernelChoice choice = choose_kernel(plan, a);
-  const bool use_fused = choice == KERNEL_FUSED_F64;
+  const bool use_fused = choice != KERNEL_GENERIC;
   if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch
     if (batch > plan->desc.max_batch) return fail(MO_ERR_INVALID_ARGUMENT, "batch %lld > plan max_batch %lld", (long long)batch, (long long)plan->desc.max_batch);
     const size_t n = (size_t)plan->desc.n;
@@ -461,14 +476,14 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
     const size_t per_problem = (size_t)(nt * (nt + 1) / 2) * 256 + (size_t)nt * 64;
     MO_HIP_CHECK(hipSetDevice(plan->desc.device));
     if (!plan->tile_scratch) {
-      if (hipMalloc(&plan->tile_scratch, (size_t)plan->desc.max_batch * per_problem * sizeof(double)) != hipSuccess) {
+      if (hipMalloc(&plan->tile_scratch, (size_t)plan->desc.max_batch * per_problem * plan->elem) != hipSuccess) {
         plan->tile_scratch = nullptr;  // not fatal: the kernel re-streams J instead
         (void)hipGetLastError();
       }
     }
     a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_problem;
   }
-  return launch_chosen(plan, a, choice, stream);  // fused Solve kernel (fp64, n <= 128), generic kernel otherwise
+  return launch_chosen(plan, a, choice, stream);  // fused Solve kernel (fp64: n <= 128; fp32: n = 64 / 128), generic kernel otherwise
 }
 }  // namespace
 

@@ -252,6 +252,9 @@ class QPInteriorPointSolver:
     def step_kernel(self) -> str:
         return L.lib().mo_plan_step_kernel(self._plan, C.byref(self._prob)).decode()
 
+    def solve_kernel(self) -> str:
+        return L.lib().mo_plan_solve_kernel(self._plan, C.byref(self._prob)).decode()
+
     def _mu_arg(self, mu):
         if isinstance(mu, torch.Tensor):
             assert mu.dtype == self.p_.dtype and mu.is_cuda and mu.is_contiguous()

@@ -654,6 +654,82 @@ def test_fused_f32_status_words():
     assert np.all(np.isnan(dn[[1, 4, 5, 6]])) and np.all(np.isfinite(dn[good]))
 
 
+@pytest.mark.parametrize("n,k,m,m_r,level", [(128, 16, 64, 256, "J"), (128, 0, 0, 128, "J"), (128, 16, 3, 132, "J"), (64, 8, 32, 128, "J"),
+                                             (64, 16, 0, 64, "J"), (64, 0, 17, 260, "J"), (128, 16, 64, 0, "QP"), (64, 5, 20, 0, "QP")])
+def test_fused_f32_solve_iterate_residual(n, k, m, m_r, level):
+    """kkt_fused_f32_solve_kernel: EvaluateKKTConditions, Iterate (all three barrier strategies) and the whole Solve in fp32 for the
+    n = 64 / 128 tile grids -- BASELINE configs[3] in every mode -- against the fp64 fused kernels on the same (fp32-rounded) inputs
+    (those are pinned to the oracle above) and against the generic fp32 kernel.  fp32 has no reference counterpart; tolerances are
+    fp32 ones (2e-3 rel-inf for directions and states, as for the step kernel)."""
+    rng = np.random.default_rng(n * 1000 + k * 100 + m + m_r)
+    B = 13
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    mr = m_r if m_r else 2 * n
+    J = f(rng.uniform(-1, 1, (B, mr, n))); r = f(rng.uniform(-1, 1, (B, mr)))
+    A = f(rng.uniform(-1, 1, (B, n, k))); b = f(0.3 * rng.uniform(-1, 1, (B, k)))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32)
+    ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = f(rng.uniform(0.5, 2.0, (B, m)))
+    x = f(rng.uniform(-0.1, 0.1, (B, n)))
+    sl = f(rng.uniform(0.2, 1.5, (B, m))); z = f(rng.uniform(0.1, 2, (B, m))); y = f(rng.uniform(-1, 1, (B, k)))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    mu = np.full(B, float(np.float32(0.05)))
+    lam = float(np.float32(1e-2))
+    G = f(np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)); c = f(np.einsum("bqi,bq->bi", J, r))
+
+    def problem(dt):
+        common = dict(A_eq=T(A, dt) if k else None, b_eq=T(b, dt) if k else None, cons_var=T(cv, torch.int32) if m else None,
+                      cons_a=T(ca, dt) if m else None, cons_b=T(cb, dt) if m else None)
+        if level == "J":
+            return Q.BatchedQP(n=n, k=k, m=m, J=T(J, dt), r=T(r, dt), lam=lam, **common)
+        return Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1), dt), c=T(c, dt), **common)
+
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=2e-3, termination_complementarity_tol=1e-3, max_iterations=14,
+              initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+    res = {}
+    for label, dt, force in (("f32", torch.float32, False), ("f64", torch.float64, False), ("generic32", torch.float32, True)):
+        s = Q.QPInteriorPointSolver(problem(dt), force_generic=force)
+        out = {}
+        s.SetVariables(T(vars_, dt))
+        out["res"] = [t.double().cpu().numpy().copy() for t in s.EvaluateKKTConditions(T(mu, dt))]
+        out["res_eq"] = [t.double().cpu().numpy().copy() for t in s.EvaluateKKTConditions(T(mu, dt), include_inequalities=False)]
+        for strategy in (Q.COMPLEMENTARITY, Q.FIXED_DECREASE, Q.PREDICTOR_CORRECTOR):
+            s.SetVariables(T(vars_, dt))
+            ip, st = s.Iterate(T(mu, dt), strategy)
+            assert torch.all(st == 0), (label, strategy)
+            out["it", strategy] = (ip.double().cpu().numpy().copy(), s.variables().double().cpu().numpy().copy(), s.delta_.double().cpu().numpy().copy())
+        for strategy in (Q.COMPLEMENTARITY, Q.PREDICTOR_CORRECTOR):
+            o = s.Solve(Q.Params(barrier_strategy=strategy, **kw))
+            assert torch.all(o.status == 0), (label, strategy)
+            out["solve", strategy] = (s.variables().double().cpu().numpy().copy(), o.num_iterations.cpu().numpy(), o.termination_state.cpu().numpy(),
+                                      o.iterations.double().cpu().numpy())
+        res[label] = out
+    f32, f64, g32 = res["f32"], res["f64"], res["generic32"]
+    keep = np.r_[0:n, n + m:n + m + k]
+    for other, tol in ((f64, 2e-4), (g32, 2e-4)):
+        scale = max(1.0, np.abs(other["res"][0]).max())
+        np.testing.assert_allclose(f32["res"][0], other["res"][0], rtol=tol, atol=tol * scale)
+        np.testing.assert_allclose(f32["res"][1], other["res"][1], rtol=10 * tol, atol=tol * scale)
+        np.testing.assert_allclose(f32["res_eq"][0][:, keep], other["res_eq"][0][:, keep], rtol=tol, atol=tol * scale)
+        np.testing.assert_allclose(f32["res_eq"][1][:, [0, 2]], other["res_eq"][1][:, [0, 2]], rtol=10 * tol, atol=tol * scale)
+        for strategy in (Q.COMPLEMENTARITY, Q.FIXED_DECREASE, Q.PREDICTOR_CORRECTOR):
+            a_, b_ = f32["it", strategy], other["it", strategy]
+            assert rel_inf_rows(a_[2], b_[2]).max() < TOL32, strategy                    # delta_
+            np.testing.assert_allclose(a_[0], b_[0], rtol=5e-3, atol=5e-3, equal_nan=True)  # mu, alphas, probe alphas, mu_affine
+            assert rel_inf_rows(a_[1], b_[1]).max() < 5e-3, strategy                     # state after the step
+    for strategy in (Q.COMPLEMENTARITY, Q.PREDICTOR_CORRECTOR):
+        xs_, nit, tm, rec = f32["solve", strategy]
+        x64, nit64, tm64, _ = f64["solve", strategy]
+        conv = (tm == Q.SATISFIED_KKT_TOL) & (tm64 == Q.SATISFIED_KKT_TOL)
+        assert conv.mean() >= 0.75, (strategy, tm, tm64)
+        assert np.abs(nit[conv] - nit64[conv]).max() <= 2, (nit, nit64)
+        assert np.max(np.abs(xs_[conv][:, :n] - x64[conv][:, :n])) <= 5e-3 * max(1.0, np.abs(x64[:, :n]).max())
+        # the records of the first iteration follow the fp64 ones
+        _, _, _, rec64 = f64["solve", strategy]
+        np.testing.assert_allclose(rec[:, 0, 8:11], rec64[:, 0, 8:11], rtol=5e-3, atol=5e-3)
+    s = Q.QPInteriorPointSolver(problem(torch.float32))
+    assert s.solve_kernel().startswith("fused_solve"), s.solve_kernel()
+
+
 # ------------------------------------------------------------------ fused fp64 kernels on sizes that are padded to the tile grid
 @pytest.mark.parametrize("n,k,m,m_r,level", [(20, 2, 6, 24, "J"), (34, 4, 10, 40, "J"), (46, 0, 8, 48, "J"), (62, 14, 2, 64, "J"),
                                              (2, 0, 4, 0, "QP"), (7, 2, 3, 0, "QP"), (33, 5, 12, 0, "QP"), (50, 8, 0, 0, "QP")])
