@@ -1100,6 +1100,128 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
   }
 }
 
+// Standalone linearisation in fp32 (mo_linearize, mo_fill_qp; nonlinear.cc:182-189, residual.hpp:186-226): J streams once through the
+// ring into the G tiles, which are written out as the lower triangle of the column-major n x n matrix (strict upper triangle exactly
+// zero, residual.hpp:216-220), with c = J^T r and 0.5 |r|^2.
+template <int NT, int WPS>
+__global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel(const KernelArgs a) {
+  using C = SolveCfg32<NT>;
+  constexpr int N = C::N, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
+  constexpr int WAVES = 4 * WPS;
+  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * D * SLOT];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* const smem = smem_all + wave * D * SLOT;
+  const unsigned ring_base = (unsigned)(uintptr_t)smem;
+  const int nsteps = a.m_r >> 2;
+  const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  auto chunk_for = [&](long long observed) -> int {
+    const long long c = (a.batch - observed) >> chunk_shift;
+    return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
+  };
+  auto take_ticket = [&](int chunk) -> unsigned long long {
+    unsigned long long t = 0;
+    if (lane_id32() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
+    return t;
+  };
+  auto uniform64 = [](unsigned long long v) -> long long {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  int chunk = chunk_for(0);
+  long long p = uniform64(take_ticket(chunk));
+  long long chunk_end = p + chunk;
+  while (p < a.batch) {
+    const bool last_of_chunk = p + 1 >= chunk_end;
+    int next_chunk = 0;
+    unsigned long long next_ticket = 0;
+    if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk); }
+    const int lane = lane_id32();
+    const int g = lane >> 4, j = lane & 15;
+    const char* jsrc = reinterpret_cast<const char*>((const float*)a.J + p * a.J_stride + (size_t)g * N + 4 * j);
+    const char* rsrc = reinterpret_cast<const char*>((const float*)a.r + p * a.r_stride);
+    auto issue = [&](int slot) {
+      const unsigned dst = ring_base + slot * SLOT;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) dma16_f32(jsrc + 256 * h, dst + h * 1024);
+      if (lane < 1) dma16_f32(rsrc, dst + NH * 1024);
+      jsrc += 4 * N * 4;
+      rsrc += 16;
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+      if (u < nsteps) issue(u);
+    f4 U[NT * NT];
+#pragma unroll
+    for (int q = 0; q < NT * NT; ++q) U[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const char* const lane_piece = smem + lane * 16;
+    const char* const r_elem = smem + NH * 1024 + 4 * g;
+    float cpart[NT], rsq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) cpart[c] = 0.0f;
+    for (int q0 = 0; q0 < nsteps; q0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int q = q0 + u;
+        if (q < nsteps) {
+          const int younger = nsteps - 1 - q;
+          if (younger >= D - 1) wait_vmcnt32<(D - 1) * DPS>();
+          else if (younger == 2) wait_vmcnt32<2 * DPS>();
+          else if (younger == 1) wait_vmcnt32<1 * DPS>();
+          else wait_vmcnt32<0>();
+          float ops[NT];
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            const f4 v = *(const f4*)(lane_piece + u * SLOT + h * 1024);
+            ops[4 * h] = v[0]; ops[4 * h + 1] = v[1]; ops[4 * h + 2] = v[2]; ops[4 * h + 3] = v[3];
+          }
+          const float rq = *(const float*)(r_elem + u * SLOT);
+          lds_fence32();
+          if (q + D < nsteps) issue(u);
+          rsq = fmaf(rq, rq, rsq);
+#pragma unroll
+          for (int ta = 0; ta < NT; ++ta) {
+            cpart[ta] = fmaf(ops[ta], rq, cpart[ta]);
+#pragma unroll
+            for (int tb = ta; tb < NT; ++tb)
+              U[ta * NT + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ops[ta], ops[tb], U[ta * NT + tb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    wait_vmcnt32<0>();
+    const float half_sq = 0.5f * cross_row_sum_f32(rsq);  // every lane of row g holds the sum over its rows 4s + g
+    const float lam_in = a.lambda_vec ? ((const float*)a.lambda_vec)[p * a.lambda_vec_stride] : (float)a.lambda;
+    const float lam = lam_in > 0.0f ? lam_in : 0.0f;  // nonlinear.cc:187-189
+    float* Go = (float*)a.G_out + p * a.G_out_stride;
+    const int ld = a.G_out_ld;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb) {
+        const int natc = natvar32(tb, j);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int natr = natvar32(ta, 4 * g + t);
+          const int hi = natr > natc ? natr : natc, lo = natr > natc ? natc : natr;
+          Go[hi + (size_t)lo * ld] = U[ta * NT + tb][t] + (hi == lo ? lam : 0.0f);   // lower triangle (residual.hpp:216-220)
+          if (hi != lo) Go[lo + (size_t)hi * ld] = 0.0f;                             // the strict upper triangle stays exactly zero
+        }
+      }
+    }
+    float cvec[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum_f32(cpart[c]);  // (all lanes take part in the cross-row swaps)
+    if (g == 0) {
+      float* co = (float*)a.c_out + p * a.c_out_stride;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) co[natvar32(c, j)] = cvec[c];
+    }
+    if (lane == 0 && a.half_sq_out) ((float*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = half_sq;
+    lds_fence32();
+    if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+  }
+}
+
 bool aligned16_f32(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -1107,6 +1229,10 @@ bool aligned16_f32(const void* p) { return ((uintptr_t)p & 15) == 0; }
 bool fused_f32_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F32) return false;
   if (a.n != 128 && a.n != 64) return false;
+  if (a.mode == MODE_LINEARIZE) {  // kkt_fused_f32_linearize_kernel: packed row-major J, rows in whole 4-row groups
+    return a.J && a.ticket && a.G_out && a.c_out && a.J_row_major && a.J_ld == a.n && a.m_r > 0 && !(a.m_r & 3) && aligned16_f32(a.J) &&
+           !(a.J_stride & 3) && aligned16_f32(a.r) && !(a.r_stride & 3) && a.G_out_ld >= a.n;
+  }
   if (a.k > 16 || a.m > 64 || a.m < 0) return false;
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {  // kkt_fused_f32_solve_kernel
@@ -1129,6 +1255,7 @@ bool fused_f32_supported(const KernelArgs& a, int dtype) {
 }
 
 const char* fused_f32_name(const KernelArgs& a) {
+  if (a.mode == MODE_LINEARIZE) return a.n == 128 ? "fused_linearize_f32_n128" : "fused_linearize_f32_n64";
   if (a.mode == MODE_STEP) return a.n == 128 ? "fused_mfma_f32_n128" : "fused_mfma_f32_n64";
   if (!a.J) return a.n == 128 ? "fused_solve_qp_f32_n128" : "fused_solve_qp_f32_n64";
   return a.n == 128 ? "fused_solve_mfma_f32_n128" : "fused_solve_mfma_f32_n64";
@@ -1141,6 +1268,16 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
+  if (a.mode == MODE_LINEARIZE) {
+    const int wps = a.n == 128 ? 2 : 3;
+    long long grid = num_cus;
+    const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<4, 3>), dim3((unsigned)grid), dim3(768), 0, stream, a);
+    return hipGetLastError();
+  }
   if (a.mode != MODE_STEP) {  // Solve / Iterate / KKT residual: one wave per SIMD at n = 128 (216 tile registers + the state), two at n = 64
     const int wps = a.n == 128 ? 1 : 2;
     long long grid = num_cus;

@@ -730,6 +730,30 @@ def test_fused_f32_solve_iterate_residual(n, k, m, m_r, level):
     assert s.solve_kernel().startswith("fused_solve"), s.solve_kernel()
 
 
+@pytest.mark.parametrize("n,m_r", [(128, 256), (64, 128), (128, 4), (64, 260)])
+def test_fused_f32_linearize(n, m_r):
+    """mo_linearize in fp32 on the fused kernel: G = J^T J + lambda I (lower triangle; strict upper exactly zero, residual.hpp:216-220),
+    c = J^T r, 0.5 |r|^2 -- against the fp64 products of the fp32-rounded inputs and against the generic fp32 kernel."""
+    rng = np.random.default_rng(n + m_r)
+    B = 9
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    J = f(rng.uniform(-1, 1, (B, m_r, n))); r = f(rng.uniform(-1, 1, (B, m_r)))
+    lam = float(np.float32(0.25))
+    prob = Q.BatchedQP(n=n, k=0, m=0, J=T(J, torch.float32), r=T(r, torch.float32), lam=lam)
+    G, c, half = Q.linearize(prob)
+    Gg, cg, halfg = Q.linearize(prob, force_generic=True)
+    Gn = G.double().cpu().numpy().transpose(0, 2, 1)                  # [B, row, col] of the column-major output
+    ref = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    scale = np.abs(ref).max()
+    assert np.all(np.triu(Gn, 1) == 0.0)
+    np.testing.assert_allclose(np.tril(Gn), np.tril(ref), rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(c.double().cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=0, atol=2e-6 * m_r)
+    np.testing.assert_allclose(half.double().cpu().numpy(), 0.5 * np.einsum("bq,bq->b", r, r), rtol=2e-6)
+    np.testing.assert_allclose(G.cpu().numpy(), Gg.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(c.cpu().numpy(), cg.cpu().numpy(), rtol=0, atol=2e-6 * m_r)
+    np.testing.assert_allclose(half.cpu().numpy(), halfg.cpu().numpy(), rtol=2e-6)
+
+
 # ------------------------------------------------------------------ fused fp64 kernels on sizes that are padded to the tile grid
 @pytest.mark.parametrize("n,k,m,m_r,level", [(20, 2, 6, 24, "J"), (34, 4, 10, 40, "J"), (46, 0, 8, 48, "J"), (62, 14, 2, 64, "J"),
                                              (2, 0, 4, 0, "QP"), (7, 2, 3, 0, "QP"), (33, 5, 12, 0, "QP"), (50, 8, 0, 0, "QP")])
