@@ -1278,14 +1278,14 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
     else hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<4, 3>), dim3((unsigned)grid), dim3(768), 0, stream, a);
     return hipGetLastError();
   }
-  if (a.mode != MODE_STEP) {  // Solve / Iterate / KKT residual: one wave per SIMD at n = 128 (216 tile registers + the state), two at n = 64
-    const int wps = a.n == 128 ? 1 : 2;
+  if (a.mode != MODE_STEP) {  // Solve / Iterate / KKT residual: one wave per SIMD at n = 128 (216 tile registers + the state), three at n = 64
+    const int wps = a.n == 128 ? 1 : 3;
     long long grid = num_cus;
     const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 3>), dim3((unsigned)grid), dim3(768), 0, stream, a);
     return hipGetLastError();
   }
   if (a.n == 128 && env_wps == 1) {

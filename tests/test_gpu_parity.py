@@ -754,6 +754,55 @@ def test_fused_f32_linearize(n, m_r):
     np.testing.assert_allclose(half.cpu().numpy(), halfg.cpu().numpy(), rtol=2e-6)
 
 
+@pytest.mark.parametrize("which", ["f32_cfg4", "f64_two_y_tiles"])
+@pytest.mark.parametrize("batch", [1, 12])
+def test_status_words_of_the_new_solve_kernels(which, batch):
+    """The failure channels of the reference (F_ASSERT s > 0 qp.cc:285, constraint index qp.cc:70-72, FailedFactorization / a NaN
+    in the data) inside the fp32 Solve kernel and the two-y-tile fp64 kernels: per-problem status words from Solve, Iterate and the
+    step, the healthy problems untouched; batch = 1 exercises the ticket loop with fewer problems than waves."""
+    if which == "f32_cfg4":
+        d = synth.CONFIGS["cfg4"]; n, k, m, m_r, dt = d["n"], d["k"], d["m"], d["m_r"], torch.float32
+    else:
+        n, k, m, m_r, dt = 64, 24, 40, 128, torch.float64
+    hb = synth.make_batch(n, k, m, m_r, 12, stream=5)
+    hb.vars[1, n] = 0.0                 # s = 0
+    hb.cons_var[4, 0] = n + 7           # index beyond n
+    hb.J[5, 3, 2] = np.nan              # NaN in the data
+    hb.cons_var[6, 1] = -1              # negative index
+    sel = slice(0, 12) if batch == 12 else slice(1, 2)
+    cut = lambda a_: a_[sel]
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(cut(hb.J), dt), r=T(cut(hb.r), dt), lam=hb.lam, A_eq=T(cut(hb.A_eq), dt), b_eq=T(cut(hb.b_eq), dt),
+                       cons_var=T(cut(hb.cons_var), torch.int32), cons_a=T(cut(hb.cons_a), dt), cons_b=T(cut(hb.cons_b), dt))
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.solve_kernel().startswith("fused_solve"), s.solve_kernel()
+    assert s.step_kernel().startswith("fused"), s.step_kernel()
+    checks = []
+    calls = (lambda: s.NewtonStep(T(cut(hb.mu), dt), 0.995)[2],
+             lambda: s.Iterate(T(cut(hb.mu), dt), Q.PREDICTOR_CORRECTOR)[1],
+             lambda: s.Solve(Q.Params(initial_guess_method=Q.USER_PROVIDED, max_iterations=4, termination_kkt_tol=1e-3)).status)
+    for call in calls:
+        s.SetVariables(T(cut(hb.vars), dt))
+        if batch == 1:                                           # Solve on a single problem re-throws like the reference (F_ASSERT qp.cc:285)
+            try:
+                call()
+            except L.MiniOptError as e:
+                assert "NONPOSITIVE_SLACK" in str(e)
+            checks.append(s.status_.cpu().numpy().copy())
+        else:
+            checks.append(call().cpu().numpy().copy())
+    for st in checks:
+        if batch == 1:
+            assert st.tolist() == [L.MO_STATUS_NONPOSITIVE_SLACK]
+            continue
+        good = [0, 2, 3, 7, 8, 9, 10, 11]
+        assert np.all(st[good] == 0), st
+        assert st[1] == L.MO_STATUS_NONPOSITIVE_SLACK and st[4] == L.MO_STATUS_BAD_INDEX and st[6] == L.MO_STATUS_BAD_INDEX
+        assert st[5] in (L.MO_STATUS_NONFINITE, L.MO_STATUS_FACTORIZATION_FAILED)
+    if batch == 12:
+        v = s.variables().double().cpu().numpy()
+        assert np.all(np.isfinite(v[[0, 2, 3, 7, 8, 9, 10, 11]]))
+
+
 # ------------------------------------------------------------------ fused fp64 kernels on sizes that are padded to the tile grid
 @pytest.mark.parametrize("n,k,m,m_r,level", [(20, 2, 6, 24, "J"), (34, 4, 10, 40, "J"), (46, 0, 8, 48, "J"), (62, 14, 2, 64, "J"),
                                              (2, 0, 4, 0, "QP"), (7, 2, 3, 0, "QP"), (33, 5, 12, 0, "QP"), (50, 8, 0, 0, "QP")])
