@@ -55,3 +55,80 @@ def test_random_shapes_and_layouts(seed):
         og = sg.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=10, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
         same = (out.num_iterations == og.num_iterations) & (out.termination_state == og.termination_state)
         assert same.float().mean() >= 0.8, (n, k, m, m_r, which)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
+    """Random (n, k, m, m_r, input level, barrier strategy, initial guess) through `Solve` and `Iterate` on BOTH kernel families --
+    fused and (where the shape fits its LDS) generic -- with the oracle as the referee for each: the Iterate records (mu, step lengths,
+    probe step lengths, mu_affine) and the state after it, and for Solve the termination state, the iteration count and the optimum.
+    Problems are built around a strictly feasible point with small margins so that some inequalities are active at the optimum."""
+    rng = np.random.default_rng(seed)
+    checked = {"fused": 0, "generic": 0}
+    strict = {"fused": 0, "generic": 0}
+    total = {"fused": 0, "generic": 0}
+    for trial in range(30):
+        n = int(rng.integers(2, 129)); k = int(rng.integers(0, min(32, n))); m = int(rng.integers(0, 65)); m_r = int(rng.integers(n, 2 * n + 8)); B = 4  # k < n: with k = n the equalities fix x
+        level = rng.choice(["J", "QP"]); strategy = int(rng.integers(0, 3))
+        J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+        A = rng.uniform(-1, 1, (B, n, k))
+        cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m))
+        x0 = rng.uniform(-0.5, 0.5, (B, n)); b = -np.einsum("bik,bi->bk", A, x0)
+        cb = -ca * np.take_along_axis(x0, cv.astype(np.int64), axis=1) + rng.uniform(0.05, 0.5, (B, m))
+        lam = 1e-2
+        G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); c = np.einsum("bqi,bq->bi", J, r)
+        x = rng.uniform(-0.1, 0.1, (B, n)); sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+        vars_ = np.concatenate([x, sl, y, z], axis=1)
+        common = dict(A_eq=T(A) if k else None, b_eq=T(b) if k else None, cons_var=T(cv, torch.int32) if m else None,
+                      cons_a=T(ca) if m else None, cons_b=T(cb) if m else None)
+        prob = (Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common) if level == "J"
+                else Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), **common))
+        guess = Q.SOLVE_EQUALITY_CONSTRAINED if (k and rng.integers(0, 2)) else Q.NAIVE
+        kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-6, max_iterations=12, barrier_strategy=strategy, initial_guess_method=guess)
+        # the referee
+        ref_it, ref_solve = [], []
+        for p in range(B):
+            qp = orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+            o = orc.Solver(qp)
+            o.variables[:] = vars_[p]
+            st, ip = o.iterate(0.05, strategy)
+            assert st == 0
+            ref_it.append(([ip.mu, ip.alpha_primal, ip.alpha_dual, ip.alpha_probe_primal, ip.alpha_probe_dual, ip.mu_affine], o.variables.copy()))
+            o2 = orc.Solver(qp)
+            term, its = o2.solve(**kw)
+            ref_solve.append((term, len(its), o2.variables.copy()))
+        tag = (seed, trial, level, n, k, m, m_r, strategy, guess)
+        for family, force in (("fused", False), ("generic", True)):
+            try:
+                s = Q.QPInteriorPointSolver(prob, force_generic=force)
+                s.SetVariables(T(vars_))
+                ip, st = s.Iterate(T(np.full(B, 0.05)), strategy)
+            except Exception as e:                      # the generic kernel cannot hold n + k > ~141 in LDS
+                assert force and "LDS" in str(e), (tag, e)
+                continue
+            if not force:
+                assert s.solve_kernel().startswith("fused"), (tag, s.solve_kernel())
+            assert torch.all(st == 0), (tag, family)
+            after = s.variables().cpu().numpy()
+            ipn = ip.cpu().numpy()
+            for p in range(B):
+                np.testing.assert_allclose(ipn[p], ref_it[p][0], rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=str((tag, family, p)))
+                scale = max(1.0, np.abs(ref_it[p][1]).max())
+                np.testing.assert_allclose(after[p], ref_it[p][1], rtol=1e-7, atol=1e-8 * scale, err_msg=str((tag, family, p)))
+            out = s.Solve(Q.Params(**kw))
+            assert torch.all(out.status == 0), (tag, family)
+            tm = out.termination_state.cpu().numpy(); nit = out.num_iterations.cpu().numpy(); v = s.variables().cpu().numpy()
+            for p in range(B):
+                # strict: the oracle's termination state after the oracle's iteration count.  Nearly determined problems (k close to n)
+                # sit on the tolerance for several iterations and may flip by one iteration with rounding: those must still be within one
+                # iteration and at the same point
+                strict[family] += int(tm[p] == ref_solve[p][0] and nit[p] == ref_solve[p][1])
+                total[family] += 1
+                assert abs(int(nit[p]) - ref_solve[p][1]) <= 2, (tag, family, p, tm, nit, [(t_, i_) for t_, i_, _ in ref_solve])
+                if tm[p] == Q.SATISFIED_KKT_TOL and ref_solve[p][0] == Q.SATISFIED_KKT_TOL:   # (a run that ends in MAX_ITERATIONS has no point to compare)
+                    xs = max(1.0, np.abs(ref_solve[p][2][:n]).max())
+                    assert np.abs(v[p][:n] - ref_solve[p][2][:n]).max() <= 1e-5 * xs, (tag, family, p)
+            checked[family] += 1
+    assert checked["fused"] == 30 and checked["generic"] >= 15, checked
+    for family in ("fused", "generic"):
+        assert strict[family] >= 0.93 * total[family], (family, strict, total)
