@@ -1,0 +1,40 @@
+"""bench.py's multi-rank path with REAL launches: two ranks started by torch.distributed.run share the one GPU of the test box
+(ranks wrap around the visible devices), gloo stands in for RCCL (two ranks on one device cannot form an RCCL communicator).  Everything
+else is the code the driver runs at N > 1: config-5 sharding, per-rank plans and launches, barriers, MAX / SUM, the roofline block."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_run_config5_shards():
+    env = dict(os.environ, MO_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--config", "cfg5", "--batch", "16384", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "strong"
+    assert out["config"]["name"] == "cfg5" and out["config"]["batch_per_gpu"] == 16384 and out["config"]["batch_total"] == 32768
+    assert out["config"]["kernel"] == "fused_mfma_f64_n64"
+    assert out["value"] > 1e6 and out["unit"] == "steps/s"                       # whole-job rate of both ranks
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 32768) < 1e-3 * 32768  # value = units of all ranks / max time
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    assert out["status_ok"] == out["status_total"]
