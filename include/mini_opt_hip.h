@@ -66,6 +66,7 @@ typedef enum { MO_SATISFIED_KKT_TOL = 0, MO_MAX_ITERATIONS = 1 } mo_termination;
 
 /* plan flags */
 #define MO_PLAN_FORCE_GENERIC 1u /* always use the shape-generic LDS kernel (testing / A-B measurements) */
+#define MO_PLAN_NO_TINY 2u       /* do not use the one-tile kernels for n + k <= 15 (testing / A-B: the 32-variable tile grid instead) */
 
 typedef struct {
   int32_t n;   /* variables (QPInteriorPointSolver::dims_.N, qp.cc:37) */

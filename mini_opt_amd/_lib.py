@@ -16,6 +16,7 @@ MO_OK = 0
 MO_F64, MO_F32 = 0, 1
 MO_COL_MAJOR, MO_ROW_MAJOR = 0, 1
 MO_PLAN_FORCE_GENERIC = 1
+MO_PLAN_NO_TINY = 2
 MO_STEP_NO_INEQUALITIES = 1
 (MO_STATUS_OK, MO_STATUS_NONPOSITIVE_SLACK, MO_STATUS_FACTORIZATION_FAILED, MO_STATUS_NONFINITE, MO_STATUS_BAD_INDEX,
  MO_STATUS_NOT_POSITIVE_DEFINITE) = range(6)

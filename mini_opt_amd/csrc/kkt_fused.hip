@@ -2034,6 +2034,13 @@ bool fused_supported(const KernelArgs& a, int dtype) {
 }
 
 const char* fused_name(const KernelArgs& a, int) {
+#if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)
+  if (fused_tiny_supported(a)) {  // the whole KKT system in one tile (kkt_fused_tiny.hip)
+    const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
+    if (!a.J) return solve ? "fused_solve_qp_tiny_f64" : "fused_qp_tiny_f64";
+    return solve ? "fused_solve_tiny_f64" : "fused_tiny_f64";
+  }
+#endif
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {
     if (!a.J) return a.n > 96 ? "fused_solve_qp_f64_n128" : a.n > 64 ? "fused_solve_qp_f64_n96" : a.n > 32 ? "fused_solve_qp_f64_n64" : "fused_solve_qp_f64_n32";
     return a.n > 96 ? "fused_solve_mfma_f64_n128" : a.n > 64 ? "fused_solve_mfma_f64_n96" : a.n > 32 ? "fused_solve_mfma_f64_n64" : "fused_solve_mfma_f64_n32";
@@ -2062,6 +2069,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
 #if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)  // (the diagnostic builds of tools/phase_timer*.hip link this file alone)
+  if (fused_tiny_supported(a)) return launch_fused_tiny(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && a.k > 15) return launch_fused_ny2(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && fused_needs_gather(a)) return launch_fused_gather(a, num_cus, stream);
 #endif

@@ -55,6 +55,7 @@ struct KernelArgs {
   unsigned long long* ticket;
   int stagger;     // fused step kernel: start offset between the waves that share a SIMD, in units of 127 x 64 cycles (set by launch_fused)
   int chain_prio;  // fused step kernel: s_setprio 1 while a wave is in the elimination / substitution chains
+  int no_tiny;     // MO_PLAN_NO_TINY: keep n + k <= 15 on the 32-variable tile grid (set by mo_api.hip from the plan flags)
   // diagnostics only (tools/phase_timer.hip builds kkt_fused.hip with MO_FUSED_STAMPS); NULL in the product
   unsigned long long* debug;
 };
@@ -73,6 +74,8 @@ hipError_t launch_fused(const KernelArgs& a, int dtype, int num_cus, hipStream_t
 bool fused_needs_gather(const KernelArgs& a);  // J-level input in a layout only the per-lane gather stream takes
 hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t stream);  // kkt_fused_gather.hip
 hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream);     // kkt_fused_ny2.hip: 16 <= k <= 31
+bool fused_tiny_supported(const KernelArgs& a);                                          // kkt_fused_tiny.hip: n + k <= 15, m <= 64 (a subset of fused_supported)
+hipError_t launch_fused_tiny(const KernelArgs& a, int num_cus, hipStream_t stream);
 
 
 // fused single-wave fp32 step kernel for n = 64 / 128 (J-level input), kkt_fused_f32.hip

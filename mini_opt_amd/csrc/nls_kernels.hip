@@ -143,28 +143,38 @@ __device__ inline double mod_pi(double v) {  // math::ModPi: wrap into [-pi, pi)
   const double two_pi = 6.283185307179586476925286766559, pi = 3.141592653589793238462643383279;
   return v - two_pi * floor((v + pi) / two_pi);
 }
+// LANES = 64: one wavefront per problem (lane 0 takes the scalar decisions, all lanes move the n-vectors); LANES = 1: one THREAD per
+// problem for small n -- 64 times fewer waves, and the "still searching / still active" counters are bumped once per wave instead of
+// once per problem (one word sustains ~88 M atomics/s: 65 536 single increments were 0.75 ms of a 0.75 ms launch).
+template <int LANES> __device__ inline void count_in(int* counter, bool inc) {
+  if (LANES == 64) { if (inc) atomicAdd(counter, 1); return; }
+  const unsigned long long mask = __ballot(inc);
+  if (inc && (int)(threadIdx.x & 63) == __builtin_ctzll(mask)) atomicAdd(counter, __builtin_popcountll(mask));
+}
+template <int LANES>
 __device__ inline void retract_candidate(const NlsArgs& a, long long p, double alpha, bool first, int lane) {
   const double* x = a.vars + p * a.vars_stride; const double* dx = a.qp_vars + p * a.qp_vars_stride;
   double* c = a.cand + p * a.cand_stride;
   if (a.prm.retraction == MO_RETRACT_CALLBACK) {
     if (first) {
       double* st = a.step + p * a.step_stride;
-      for (int i = lane; i < a.n; i += 64) st[i] = dx[i];
+      for (int i = lane; i < a.n; i += LANES) st[i] = dx[i];
     }
     if (lane == 0) a.step_alpha[p] = alpha;
     return;
   }
   const bool wrap = a.prm.retraction == MO_RETRACT_WRAP_PI;
-  for (int i = lane; i < a.n; i += 64) {
+  for (int i = lane; i < a.n; i += LANES) {
     const double v = x[i] + dx[i] * alpha;
     c[i] = wrap ? mod_pi(v) : v;
   }
 }
 
 // After the QP: penalty (nonlinear.cc:108-115, 485-500), directional derivative, first trial point alpha = 1 (:363, :160-168)
+template <int LANES>
 __global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = LANES == 64 ? (int)(threadIdx.x & 63) : 0;
+  const long long p = LANES == 64 ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.batch) return;
   double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
   if (si[NLS_SI_TERM] >= 0) return;  // wave-uniform
@@ -184,6 +194,7 @@ __global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) 
     }
     if (new_penalty > penalty) penalty = new_penalty * a.prm.equality_penalty_scale_factor;
   }
+  bool searching = false;
   if (lane == 0) {
     if (rec) {
       for (int i = 0; i < a.rec; ++i) rec[i] = __builtin_nan("");
@@ -203,17 +214,19 @@ __global__ __launch_bounds__(256) void nls_begin_search_kernel(const NlsArgs a) 
       sd[NLS_SD_DIRECTIONAL] = d_f + penalty * d_eq;       // DirectionalDerivatives::Total, structs.hpp:197
       sd[NLS_SD_ALPHA] = 1.0;
       si[NLS_SI_LS_RESULT] = -1; si[NLS_SI_NSTEPS] = 0;
-      atomicAdd(a.counters, 1);
+      searching = true;
     }
   }
   if (qp_status != MO_STATUS_OK) return;
-  retract_candidate(a, p, 1.0, true, lane);                                                        // alpha = 1, :363
+  retract_candidate<LANES>(a, p, 1.0, true, lane);                                                 // alpha = 1, :363
+  count_in<LANES>(a.counters, searching);
 }
 
 // One evaluation of the line search (nonlinear.cc:378-407) and, if it goes on, the next alpha (:364-376, 414-438)
+template <int LANES>
 __global__ __launch_bounds__(256) void nls_search_step_kernel(const NlsArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = LANES == 64 ? (int)(threadIdx.x & 63) : 0;
+  const long long p = LANES == 64 ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.batch) return;
   double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
   if (si[NLS_SI_TERM] >= 0 || si[NLS_SI_LS_RESULT] >= 0) return;
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(256) void nls_search_step_kernel(const NlsArgs a) {
   } else {
     next_alpha = alpha * a.prm.armijo_search_tau;          // :377-380
   }
+  bool searching = false;
   if (lane == 0) {
     const int ns = si[NLS_SI_NSTEPS];
     if (a.iterations) {
@@ -260,19 +274,22 @@ __global__ __launch_bounds__(256) void nls_search_step_kernel(const NlsArgs a) {
     sd[NLS_SD_A2] = sd[NLS_SD_A1]; sd[NLS_SD_T2] = sd[NLS_SD_T1];
     sd[NLS_SD_A1] = alpha; sd[NLS_SD_T1] = phi1;
     if (result >= 0) si[NLS_SI_LS_RESULT] = result;
-    else { sd[NLS_SD_ALPHA] = next_alpha; atomicAdd(a.counters, 1); }
+    else { sd[NLS_SD_ALPHA] = next_alpha; searching = true; }
   }
   if (result >= 0) return;
-  retract_candidate(a, p, next_alpha, false, lane);                                               // RetractCandidateVars, :160-168
+  retract_candidate<LANES>(a, p, next_alpha, false, lane);                                        // RetractCandidateVars, :160-168
+  count_in<LANES>(a.counters, searching);
 }
 
 // UpdateLambdaAndCheckExitConditions (nonlinear.cc:296-339) + the bookkeeping of the outer loop (:121-157)
+template <int LANES>
 __global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = LANES == 64 ? (int)(threadIdx.x & 63) : 0;
+  const long long p = LANES == 64 ? (long long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.batch) return;
   double* sd = a.sd + p * NLS_SD; int* si = a.si + p * NLS_SI;
   const bool was_active = si[NLS_SI_TERM] < 0;
+  bool still_active = false;
   if (was_active) {
     const int result = si[NLS_SI_LS_RESULT];
     const double* e0 = a.errors_pre + 2 * p;
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
     int state = si[NLS_SI_STATE], term = -1;
     if (result == MO_LS_SUCCESS) {
       double* x = a.vars + p * a.vars_stride; const double* c = a.cand + p * a.cand_stride;
-      for (int i = lane; i < a.n; i += 64) x[i] = c[i];                                            // variables_.swap(candidate_vars_), :303
+      for (int i = lane; i < a.n; i += LANES) x[i] = c[i];                                         // variables_.swap(candidate_vars_), :303
       lambda = fmax(lambda * (state == 1 ? a.prm.lambda_decrease_on_restore : a.prm.lambda_decrease_on_success), a.prm.min_lambda);
       state = 0;
       const double* e1 = a.errors_step + 2 * p;            // the accepted step is the last one evaluated
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
         rec[0] = state; rec[7] = result; rec[8] = si[NLS_SI_NSTEPS];
       }
       if (term >= 0) si[NLS_SI_TERM] = term;
-      else atomicAdd(a.counters + 1, 1);
+      else still_active = true;
     }
   }
   if (lane == 0) {
@@ -309,6 +326,7 @@ __global__ __launch_bounds__(256) void nls_update_kernel(const NlsArgs a) {
     if (a.termination) a.termination[p] = t >= 0 ? t : MO_NLS_MAX_ITERATIONS;                     // :157
     if (a.num_iterations) a.num_iterations[p] = si[NLS_SI_NITER];
   }
+  count_in<LANES>(a.counters + 1, still_active);
 }
 
 // SetUserExitCallback (nonlinear.cc:142-149): a problem that is still active and whose flag the callback set ends with USER_CALLBACK
@@ -358,18 +376,25 @@ hipError_t launch_nls_init(const NlsArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(nls_init_kernel, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
+// one thread per problem up to 32 variables, one wavefront per problem beyond
+#define MO_NLS_LAUNCH(KERNEL)                                                                                              \
+  do {                                                                                                                     \
+    if (a.n <= 32) hipLaunchKernelGGL(KERNEL<1>, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);        \
+    else hipLaunchKernelGGL(KERNEL<64>, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);                     \
+  } while (0)
 hipError_t launch_nls_begin_search(const NlsArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(nls_begin_search_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  MO_NLS_LAUNCH(nls_begin_search_kernel);
   return hipGetLastError();
 }
 hipError_t launch_nls_search_step(const NlsArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(nls_search_step_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  MO_NLS_LAUNCH(nls_search_step_kernel);
   return hipGetLastError();
 }
 hipError_t launch_nls_update(const NlsArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(nls_update_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, stream, a);
+  MO_NLS_LAUNCH(nls_update_kernel);
   return hipGetLastError();
 }
+#undef MO_NLS_LAUNCH
 hipError_t launch_nls_user_exit(const NlsArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(nls_user_exit_kernel, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();

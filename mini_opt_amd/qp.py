@@ -191,9 +191,10 @@ class FailedFactorization(RuntimeError):
 class QPInteriorPointSolver:
     """Batched mirror of mini_opt::QPInteriorPointSolver (qp.hpp:132-295)."""
 
-    def __init__(self, problem: Optional[BatchedQP] = None, batch: Optional[int] = None, force_generic: bool = False):
+    def __init__(self, problem: Optional[BatchedQP] = None, batch: Optional[int] = None, force_generic: bool = False, no_tiny: bool = False):
         self._plan = None
         self._force_generic = force_generic
+        self._no_tiny = no_tiny
         self.p_: Optional[BatchedQP] = None
         if problem is not None:
             self.Setup(problem, batch)
@@ -208,7 +209,7 @@ class QPInteriorPointSolver:
         ref = problem._any()
         self.batch = int(batch if batch is not None else ref.shape[0])
         desc = L.PlanDesc(problem.n, problem.k, problem.m, problem.m_r, _DT[problem.dtype],
-                          ref.device.index or 0, L.MO_PLAN_FORCE_GENERIC if self._force_generic else 0, 0, self.batch)
+                          ref.device.index or 0, (L.MO_PLAN_FORCE_GENERIC if self._force_generic else 0) | (L.MO_PLAN_NO_TINY if self._no_tiny else 0), 0, self.batch)
         plan = C.c_void_p()
         L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
         self._plan = plan

@@ -1229,7 +1229,7 @@ def test_fused_odd_n_with_stacked_jacobian(n, k, m, m_r):
     lam = 0.3 if m_r < n else 1e-3
     prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
                        cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca) if m else None, cons_b=T(cb) if m else None)
-    s = Q.QPInteriorPointSolver(prob)
+    s = Q.QPInteriorPointSolver(prob, no_tiny=True)               # (the smallest shapes would otherwise run on the one-tile kernel)
     assert s.step_kernel().startswith("fused_mfma"), s.step_kernel()
     s.SetVariables(T(vars_))
     delta, alpha, status = s.NewtonStep(T(mu), 0.995)

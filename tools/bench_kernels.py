@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--no-records", action="store_true", help="Solve without the per-iteration records")
     ap.add_argument("--layout", default="packed", choices=["packed", "col", "rowld"],
                     help="layout of J: packed row-major (16-byte stream), column-major or row-major with ld = n + 2 (gather stream)")
+    ap.add_argument("--no-tiny", action="store_true", help="keep n + k <= 15 on the 32-variable tile grid (MO_PLAN_NO_TINY)")
     ap.add_argument("--shape", default="", help="n,k,m,m_r in fp64 instead of a named config (e.g. 64,24,32,128: the two-y-tile kernels)")
     args = ap.parse_args()
     d = synth.CONFIGS[args.config]
@@ -46,7 +47,7 @@ def main():
         prob.J = wide
     extra = {}
     if args.mode in ("step", "generic"):
-        s = Q.QPInteriorPointSolver(prob, force_generic=args.mode == "generic")
+        s = Q.QPInteriorPointSolver(prob, force_generic=args.mode == "generic", no_tiny=args.no_tiny)
         s.SetVariables(vars_)
         kernel = s.step_kernel()
         fn = lambda: s.NewtonStep(mu, 0.995)
@@ -66,7 +67,7 @@ def main():
         ps = q.as_struct()
         fn = lambda: L.check(lib.mo_linearize(plan, C.byref(ps), batch, Q._ptr(G), n * n, n, Q._ptr(c), n, Q._ptr(f), Q._stream()))
     else:
-        s = Q.QPInteriorPointSolver(prob)
+        s = Q.QPInteriorPointSolver(prob, no_tiny=args.no_tiny)
         kernel = "solve:" + s.step_kernel()
         params = Q.Params(initial_mu=1.0, sigma=0.1, max_iterations=10,
                           barrier_strategy=Q.PREDICTOR_CORRECTOR if args.mode == "solve_pc" else Q.COMPLEMENTARITY,
