@@ -40,7 +40,7 @@ BASELINE_INDEX = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}
 def kernel_source_digest() -> str:
     """sha256 over the kernel sources: a committed PMC summary is only quoted while the kernels it measured are unchanged."""
     h = hashlib.sha256()
-    for name in ("kkt_fused.hip", "kkt_fused_f32.hip", "kkt_generic.hip", "mo_kernels.h"):
+    for name in ("kkt_fused.hip", "kkt_fused_f32.hip", "kkt_generic.hip", "mo_kernels.h"):  # (the step kernel of every BASELINE config lives in these)
         with open(os.path.join(ROOT, "mini_opt_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

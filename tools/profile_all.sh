@@ -21,4 +21,5 @@ else
   $P r02_linearize_f32_cfg4 --batch 65536 -- tools/bench_kernels.py --mode linearize --config cfg4
   $P r02_step_k24 --batch 65536 -- tools/bench_kernels.py --mode step --shape 64,24,32,128
   $P r02_solve_k24 --batch 65536 -- tools/bench_kernels.py --mode solve --shape 64,24,32,128
+  $P r02_solve_tiny --batch 65536 -- tools/bench_kernels.py --mode solve --shape 8,2,4,16
 fi
