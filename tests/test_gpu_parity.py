@@ -880,7 +880,18 @@ def test_fused_two_y_tiles_vs_generic_random_shapes():
         _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=True, kkt_tol=1e-6)
 
 
-def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-8):
+@pytest.mark.parametrize("level,n,k,m,m_r", [("J", 15, 0, 0, 15), ("J", 13, 2, 64, 64), ("J", 2, 1, 1, 1), ("J", 8, 7, 5, 3), ("QP", 14, 1, 64, 0),
+                                               ("QP", 2, 0, 0, 0), ("J", 8, 2, 4, 16), ("J", 5, 0, 64, 64), ("QP", 9, 6, 30, 0)])
+def test_one_tile_kernel_at_its_boundaries(level, n, k, m, m_r):
+    """kkt_fused_tiny.hip at the edges of its range: n + k = 15 (the last free tile column carries the right-hand side), k = 0, m = 0,
+    m = 64, m_r = 64 and 1, k = n - 1, and BASELINE configs[0] itself (n = 8, 2 equalities, 4 box entries) -- step, step without
+    inequalities, KKT residual, Iterate and Solve against the generic kernel (pinned to the oracle), and the same problems on the
+    32-variable tile grid (MO_PLAN_NO_TINY) must give the same Solve."""
+    rng = np.random.default_rng(100 * n + 10 * k + m)
+    _fused_vs_generic_case(rng, level, n, k, m, m_r if m_r else 2 * n, feasible=True, expect_kernel="tiny")
+
+
+def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-8, expect_kernel=None):
         B = 9
         J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
         A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
@@ -909,6 +920,8 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
             s = Q.QPInteriorPointSolver(prob, force_generic=force)
             if not force:
                 assert s.step_kernel().startswith("fused"), (tag, s.step_kernel())
+                if expect_kernel:
+                    assert expect_kernel in s.step_kernel() and expect_kernel in s.solve_kernel(), (tag, s.step_kernel(), s.solve_kernel())
             s.SetVariables(T(vars_))
             delta, alpha, status = s.NewtonStep(T(mu), 0.995)
             assert torch.all(status == 0), tag
@@ -949,6 +962,17 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
         if conv.any():
             xa, xb_ = f[4][conv][:, :n], g_[4][conv][:, :n]
             assert np.max(np.abs(xa - xb_)) <= 1e-5 * max(1.0, np.max(np.abs(xb_))), tag
+        if expect_kernel == "tiny":   # the same problems on the 32-variable grid
+            s32 = Q.QPInteriorPointSolver(prob, no_tiny=True)
+            assert "tiny" not in s32.solve_kernel() and s32.solve_kernel().startswith("fused"), s32.solve_kernel()
+            o32 = s32.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=kkt_tol, max_iterations=10, barrier_strategy=strategy,
+                                     initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
+            same32 = (o32.num_iterations.cpu().numpy() == f[5]) & (o32.termination_state.cpu().numpy() == f[6])
+            assert same32.mean() >= 0.75, (tag, o32.num_iterations, f[5])
+            c32 = same32 & (f[6] == Q.SATISFIED_KKT_TOL)
+            if c32.any():
+                x32 = s32.variables().cpu().numpy()[c32][:, :n]
+                assert np.max(np.abs(x32 - f[4][c32][:, :n])) <= 1e-5 * max(1.0, np.max(np.abs(x32))), tag
 
 
 @pytest.mark.parametrize("n,k,m,m_r,level", [(66, 4, 10, 72, "J"), (96, 8, 32, 192, "J"), (100, 14, 64, 200, "J"), (128, 10, 40, 256, "J"),
