@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_tiny_kernel(const KernelAr
   // guided tickets (a quarter of the remaining share per wave, at least one problem); with `skip` words at least eight, so that a launch
   // whose problems are mostly finished does not spend its time on the counter
   const long long per_wave = batch / ((long long)gridDim.x * WAVES);
-  const int floor_chunk = (a.skip && per_wave >= 8) ? 8 : 1;
+  const bool sparse = a.skip_active >= 0 && a.skip_active * 8 < batch;  // mostly finished: whole-wave tickets, the skip scan is what costs
+  const int floor_chunk = (a.skip && per_wave >= 8) ? (sparse ? 64 : 8) : 1;
   auto chunk_for = [&](long long observed) -> int {
     const long long c = (batch - observed) >> chunk_shift;
     return c < floor_chunk ? floor_chunk : (c > 64 ? 64 : (int)c);

@@ -427,7 +427,7 @@ int mo_iterate(mo_plan* plan, const mo_problem* prob, int64_t batch, void* vars,
 namespace {
 int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_solve_params* params, void* vars,
                   int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
-                  int32_t* status, const int* skip, long long skip_stride, void* stream) {
+                  int32_t* status, const int* skip, long long skip_stride, long long skip_active, void* stream) {
   g_err[0] = 0;
   if (int rc = check_plan(plan)) return rc;
   if (!params) return fail(MO_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -448,7 +448,7 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
   a.sp = *params;
   a.termination = termination; a.num_iterations = num_iterations; a.iterations = iterations; a.lagrange = lagrange;
   a.status = status;
-  a.skip = skip; a.skip_stride = skip_stride;
+  a.skip = skip; a.skip_stride = skip_stride; a.skip_active = skip_active;
   a.ticket = plan->ticket; a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   const KernelChoice choice = choose_kernel(plan, a);
   const bool use_fused = choice != KERNEL_GENERIC;
@@ -492,7 +492,7 @@ extern "C" {
 int mo_qp_solve(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo_solve_params* params, void* vars,
                 int64_t vars_stride, int32_t* termination, int32_t* num_iterations, void* iterations, void* lagrange,
                 int32_t* status, void* stream) {
-  return qp_solve_impl(plan, prob, batch, params, vars, vars_stride, termination, num_iterations, iterations, lagrange, status, nullptr, 0,
+  return qp_solve_impl(plan, prob, batch, params, vars, vars_stride, termination, num_iterations, iterations, lagrange, status, nullptr, 0, -1,
                        stream);
 }
 
@@ -675,6 +675,7 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
   da.out2 = deriv; da.quad_out = quad;
 
   int host_counters[2];
+  long long still_active = batch;  // problems the previous outer iteration left active (a hint for the QP kernel's ticket size)
   for (int iter = 0; iter < prm->max_iterations; ++iter) {
     na.iter = iter;
     if (eval(user, MO_NLS_EVAL_LINEARIZE, stream) != 0) return fail(MO_ERR_CALLBACK, "eval(LINEARIZE) failed at iteration %d", iter);
@@ -696,7 +697,7 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
     } else {
       void* qp_records = np->qp_iterations ? (void*)((double*)np->qp_iterations + (size_t)iter * (size_t)batch * sp.max_iterations * MO_ITER_RECORD) : nullptr;
       if (int rc = qp_solve_impl(plan, &qp, batch, &sp, qp_vars, Vs, qp_term, qp_nit, qp_records, lagrange, qp_status,
-                                 si + mo::NLS_SI_TERM, mo::NLS_SI, stream)) return rc;  // terminated problems are skipped
+                                 si + mo::NLS_SI_TERM, mo::NLS_SI, still_active, stream)) return rc;  // terminated problems are skipped
       if (np->qp_lagrange && k > 0)
         MO_HIP_CHECK(hipMemcpyAsync((double*)np->qp_lagrange + (size_t)iter * (size_t)batch * 2, lagrange, sizeof(double) * 2 * (size_t)batch,
                                     hipMemcpyDeviceToDevice, s));
@@ -726,6 +727,7 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
     MO_HIP_CHECK(hipMemcpyAsync(host_counters, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MO_HIP_CHECK(hipStreamSynchronize(s));
     if (host_counters[1] == 0) break;  // every problem has terminated
+    still_active = host_counters[1];
   }
   MO_HIP_CHECK(hipStreamSynchronize(s));  // the scratch is released on return
   return MO_OK;

@@ -51,6 +51,7 @@ struct KernelArgs {
   int* termination; int* num_iterations; void* iterations; void* lagrange;
   // MODE_SOLVE inside mo_nls_solve: problems whose word skip[p * skip_stride] is >= 0 have terminated and are left untouched
   const int* skip; long long skip_stride;
+  long long skip_active;  // how many of them are still active (host-side count from the previous outer iteration; -1: unknown)
   // fused kernel: device work counter (plan-owned, zeroed on the launch stream before every launch)
   unsigned long long* ticket;
   int stagger;     // fused step kernel: start offset between the waves that share a SIMD, in units of 127 x 64 cycles (set by launch_fused)
