@@ -236,9 +236,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_tiny_kernel(const KernelAr
         const double sq = r16 * r16;
         n_rd2 = readlane_f64(row_sum(j < n ? sq : 0.0), 0);
         n_rpe2 = readlane_f64(row_sum(j >= n ? sq : 0.0), 0);
-        n_rc2 = wave_sum_f64(r_comp * r_comp);
-        n_rc1 = wave_sum_f64(r_comp);
-        n_rpi2 = wave_sum_f64(r_pi * r_pi);
+        if (m > 0) {  // wave-uniform
+          n_rc2 = wave_sum_f64(r_comp * r_comp);
+          n_rc1 = wave_sum_f64(r_comp);
+          n_rpi2 = wave_sum_f64(r_pi * r_pi);
+        }
       }
       if (residual_mode) {  // r_ = [r_d | r_comp | r_pe | r_pi] (qp.cc:391-420) and the four norms of ComputeErrors (qp.cc:423-437)
         double* ro = (double*)ka->r_out + p * ka->r_out_stride;
@@ -345,8 +347,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_tiny_kernel(const KernelAr
           finite = finite && (fabs(dsv) < INFINITY) && (fabs(dzv) < INFINITY);
         }
         if (!__all(finite)) return false;
-        ap = cross_row_min(row_min(ap));
-        ad = cross_row_min(row_min(ad));
+        if (m > 0) {  // wave-uniform
+          ap = cross_row_min(row_min(ap));
+          ad = cross_row_min(row_min(ad));
+        }
         lds_fence();
         return true;
       };
