@@ -8,14 +8,19 @@ import torch
 from mini_opt_amd import qp as Q
 from oracle import oracle as orc
 
+import os
+
 pytestmark = pytest.mark.gpu
+# MO_FUZZ_EXTRA_SEEDS="100-140" widens both sweeps for a one-off soak run (not part of the default suite)
+_extra = os.environ.get("MO_FUZZ_EXTRA_SEEDS", "")
+EXTRA_SEEDS = list(range(int(_extra.split("-")[0]), int(_extra.split("-")[1]) + 1)) if _extra else []
 
 
 def T(a, dt=torch.float64):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3] + EXTRA_SEEDS)
 def test_random_shapes_and_layouts(seed):
     rng = np.random.default_rng(seed)
     worst = 0.0
@@ -57,7 +62,7 @@ def test_random_shapes_and_layouts(seed):
         assert same.float().mean() >= 0.8, (n, k, m, m_r, which)
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12] + EXTRA_SEEDS)
 def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
     """Random (n, k, m, m_r, input level, barrier strategy, initial guess) through `Solve` and `Iterate` on BOTH kernel families --
     fused and (where the shape fits its LDS) generic -- with the oracle as the referee for each: the Iterate records (mu, step lengths,
@@ -68,7 +73,10 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
     strict = {"fused": 0, "generic": 0}
     total = {"fused": 0, "generic": 0}
     for trial in range(30):
-        n = int(rng.integers(2, 129)); k = int(rng.integers(0, min(32, n))); m = int(rng.integers(0, 65)); m_r = int(rng.integers(n, 2 * n + 8)); B = 4  # k < n: with k = n the equalities fix x
+        n = int(rng.integers(2, 129)); B = 4
+        # well-posed problems: at most n / 2 equalities and 2 n inequality entries.  (With k close to n or m >> n the start has slacks clamped at
+        # 1e-9, z = 1e9, and three correct implementations follow three different trajectories -- seen in a 40-seed soak of this test.)
+        k = int(rng.integers(0, min(32, n // 2 + 1))); m = int(rng.integers(0, min(65, 2 * n + 1))); m_r = int(rng.integers(n, 2 * n + 8))
         level = rng.choice(["J", "QP"]); strategy = int(rng.integers(0, 3))
         J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
         A = rng.uniform(-1, 1, (B, n, k))
