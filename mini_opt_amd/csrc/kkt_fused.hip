@@ -304,7 +304,7 @@ __device__ inline void dma4(const void* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
-// `count` consecutive doubles (count <= 128, wave-uniform) from global memory to LDS without touching a VGPR destination.
+// `count` consecutive doubles (count <= 256, wave-uniform) from global memory to LDS without touching a VGPR destination.
 // `src` must be wave-uniform.
 __device__ inline void dma_doubles(const double* src, unsigned lds_dst, int count, int lane) {
   const unsigned voff = 4u * (unsigned)lane;
@@ -313,6 +313,11 @@ __device__ inline void dma_doubles(const double* src, unsigned lds_dst, int coun
   if (count > 64) {  // wave-uniform; up to 128 doubles (n = 96 / 128)
     if (lane + 128 < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 512, voff, lds_dst + 512);
     if (lane + 192 < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 768, voff, lds_dst + 768);
+  }
+  if (count > 128) {  // wave-uniform; up to 256 doubles (four constraint slots per lane)
+#pragma unroll
+    for (int c = 4; c < 8; ++c)
+      if (lane + 64 * c < 2 * count) dma4_s(reinterpret_cast<const char*>(src) + 256 * c, voff, lds_dst + 256 * c);
   }
 }
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -1044,7 +1049,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     if (m > 0) {
       const long long coff = p * ka->cons_stride;
       if (lane < m) dma4_s(ka->cons_var + coff, 4u * (unsigned)lane, vec_base + (3 * N + 4 * MCAP) * 8);
-      if (MC > 1 && lane + 64 < m) dma4_s(ka->cons_var + coff + 64, 4u * (unsigned)lane, vec_base + (3 * N + 4 * MCAP) * 8 + 256);
+#pragma unroll
+      for (int ci = 1; ci < MC; ++ci)
+        if (lane + 64 * ci < m) dma4_s(ka->cons_var + coff + 64 * ci, 4u * (unsigned)lane, vec_base + (3 * N + 4 * MCAP) * 8 + 256 * ci);
       dma_doubles((const double*)ka->cons_a + coff, vec_base + (3 * N) * 8, m, lane);
       dma_doubles((const double*)ka->cons_b + coff, vec_base + (3 * N + MCAP) * 8, m, lane);
       dma_doubles(vp + nn, vec_base + (3 * N + 2 * MCAP) * 8, m, lane);                      // s
@@ -2019,8 +2026,10 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.mode == MODE_RESIDUAL && !a.r_out) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.k > 31 || a.m < 0) return false;  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31
-  // two constraint slots per lane (m <= 128): the step kernel on every tile grid, Solve / Iterate on the 32 / 64 grids
-  if (a.m > ((a.mode == MODE_STEP || a.n <= 64) ? 128 : 64)) return false;
+  // up to four constraint slots per lane: m <= 256 (beyond 128, and beyond 64 for Solve / Iterate on the 96 / 128 grids: kkt_fused_mc4.hip)
+  if (a.m > 256) return false;
+  if (a.m > 128 && (a.k > 15 || (a.J && (a.n & 1)))) return false;  // the two-y-tile and the flat-stream kernels carry at most two / one slot
+  if (a.k > 15 && a.m > 64 && a.n > 64 && a.mode != MODE_STEP) return false;  // two y tiles on the 96 / 128 grids: Solve / Iterate carry one slot
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of a packed row-major J (even n), the flat-group stream (odd n <= 64), or the gather stream
@@ -2070,6 +2079,9 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   if (e != hipSuccess) return e;
 #if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)  // (the diagnostic builds of tools/phase_timer*.hip link this file alone)
   if (fused_tiny_supported(a)) return launch_fused_tiny(a, num_cus, stream);
+  if (a.mode != MODE_LINEARIZE && a.k <= 15 && !fused_needs_gather(a) && !(a.J && (a.n & 1)) &&
+      (a.m > 128 || (a.m > 64 && a.n > 64 && a.mode != MODE_STEP)))
+    return launch_fused_mc4(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && a.k > 15) return launch_fused_ny2(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && fused_needs_gather(a)) return launch_fused_gather(a, num_cus, stream);
 #endif

@@ -221,8 +221,8 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   memset(&a, 0, sizeof(a));
   a.n = desc->n; a.k = desc->k; a.m = desc->m; a.m_r = desc->m_r;
   p->generic_lds = mo::generic_lds_bytes(a, p->elem);
-  // fp64 systems up to n = 128 (k <= 31, m <= 64; m <= 128 for the step) run on the fused kernels even when the LDS-resident generic kernel cannot hold them
-  const bool fused_capable = desc->dtype == MO_F64 && desc->n <= 128 && desc->k <= 31 && desc->m <= 128;
+  // fp64 systems up to n = 128 (k <= 31, m <= 256) run on the fused kernels even when the LDS-resident generic kernel cannot hold them
+  const bool fused_capable = desc->dtype == MO_F64 && desc->n <= 128 && desc->k <= 31 && desc->m <= 256;
   if (p->generic_lds > 160 * 1024 && !fused_capable) {
     const size_t need = p->generic_lds;
     (void)hipFree(p->ticket);

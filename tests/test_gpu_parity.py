@@ -1186,6 +1186,66 @@ def test_fused_solve_with_up_to_128_constraints(n, k, m, m_r, level, strategy):
             np.testing.assert_allclose(f[5][p][i], exp, rtol=1e-6, atol=1e-9 + 1e-12 * scale, equal_nan=True)
 
 
+@pytest.mark.parametrize("n,k,m,m_r,level", [(128, 14, 256, 256, "J"), (64, 8, 200, 128, "J"), (30, 3, 256, 0, "QP"), (96, 8, 160, 192, "J"),
+                                             (128, 10, 100, 256, "J"), (96, 6, 128, 0, "QP"), (100, 4, 129, 0, "QP"), (32, 4, 130, 64, "J")])
+def test_fused_four_constraint_slots(n, k, m, m_r, level):
+    """128 < m <= 256 (a two-sided box on every one of 128 variables is m = 256) and Solve / Iterate with m > 64 on the 96 / 128 tile grids:
+    the instantiations of kkt_fused_mc4.hip.  Step, Iterate (predictor-corrector) and the whole Solve against the oracle, problem by problem
+    -- the LDS-resident generic kernel cannot hold most of these shapes at all."""
+    rng = np.random.default_rng(n + 7 * m)
+    B = 6
+    mr = m_r if m_r else 2 * n
+    J = rng.uniform(-1, 1, (B, mr, n)); r = rng.uniform(-1, 1, (B, mr))
+    A = rng.uniform(-1, 1, (B, n, k)); b = 0.1 * rng.uniform(-1, 1, (B, k))
+    cv = (np.arange(m)[None, :] // 2 % n + np.zeros((B, 1), int)).astype(np.int32)           # a box per variable, wrapping around
+    ca = np.where(np.arange(m) % 2 == 0, 1.0, -1.0)[None, :] * np.ones((B, 1)); cb = rng.uniform(1.0, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n))
+    sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1)
+    mu = np.full(B, 0.05)
+    lam = 1e-3
+    G = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    c = np.einsum("bqi,bq->bi", J, r)
+    common = dict(A_eq=T(A), b_eq=T(b), cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    prob = (Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, **common) if level == "J"
+            else Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1)), c=T(c), **common))
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel().startswith("fused") and s.solve_kernel().startswith("fused"), (s.step_kernel(), s.solve_kernel())
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, G=np.tril(G).transpose(0, 2, 1).copy(), c=c, A_eq=A, b_eq=b, cons_var=cv,
+                                                            cons_a=ca, cons_b=cb, vars_=vars_, mu=mu)
+    assert torch.all(status == 0) and np.all(ref_status == 0)
+    assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-9
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED)
+    for strategy in (Q.COMPLEMENTARITY, Q.PREDICTOR_CORRECTOR):
+        s.SetVariables(T(vars_))
+        ip, st = s.Iterate(T(mu), strategy)
+        assert torch.all(st == 0)
+        after = s.variables().cpu().numpy().copy()
+        out = s.Solve(Q.Params(barrier_strategy=strategy, **kw))
+        assert torch.all(out.status == 0)
+        v = s.variables().cpu().numpy(); nit = out.num_iterations.cpu().numpy(); tm = out.termination_state.cpu().numpy()
+        agree = 0
+        for p in range(B):
+            qp = orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+            o = orc.Solver(qp)
+            o.variables[:] = vars_[p]
+            ost, oip = o.iterate(0.05, strategy)
+            assert ost == 0
+            np.testing.assert_allclose(ip.cpu().numpy()[p], [oip.mu, oip.alpha_primal, oip.alpha_dual, oip.alpha_probe_primal, oip.alpha_probe_dual, oip.mu_affine],
+                                       rtol=1e-6, atol=1e-9, equal_nan=True)
+            np.testing.assert_allclose(after[p], o.variables, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(o.variables).max()))
+            o2 = orc.Solver(qp)
+            term, its = o2.solve(barrier_strategy=strategy, **kw)
+            if tm[p] == term and nit[p] == len(its):
+                agree += 1
+                if term == Q.SATISFIED_KKT_TOL:
+                    np.testing.assert_allclose(v[p][:n], o2.variables[:n], rtol=1e-6, atol=1e-8)
+        assert agree >= B - 1, (strategy, tm, nit)
+
+
 def test_newton_step_is_graph_capturable():
     """mo_newton_step enqueues only a 8-byte memset and one kernel on the caller's stream: it can be captured into a HIP graph
     (torch.cuda.graph) and replayed on new data in the same buffers."""
