@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 // Standalone linearisation (mo_linearize, the cost part of mo_fill_qp): LinearizeAndFillQP's G = J^T J + lambda I (lower triangle,
 // strict upper written as 0), c = J^T r, 0.5 |r|^2 (nonlinear.cc:182-189; residual.hpp:206-224) with the same J stream as the step
 // kernel.  The tiles leave the registers through scattered 8-byte stores (position -> natural index), 64 KB per problem at n = 64.
-template <int NT, int WPS>
+template <int NT, int WPS, int JMODE = JMODE_VECTOR>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(const KernelArgs a) {
   using C = FusedCfg<NT, WPS>;
   constexpr int NB = NT + 1, SLOT = C::SLOT, D = C::D;
@@ -1326,8 +1326,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
     if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk); }
     const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
-    JStream<NT, D> stream;
-    stream.init((const double*)a.J + p * a.J_stride, (const double*)a.r + p * a.r_stride, smem, ring_base, lane, g, j, m_r, nn);
+    JStream<NT, D, JMODE> stream;
+    stream.init((const double*)a.J + p * a.J_stride, (const double*)a.r + p * a.r_stride, smem, ring_base, lane, g, j, m_r, nn,
+                a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
     stream.prologue();
     d4 U[NB * NB];
 #pragma unroll
@@ -2018,9 +2019,8 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F64) return false;
   if (a.flags & ~MO_STEP_NO_INEQUALITIES) return false;
   if (a.flags && a.mode != MODE_STEP && a.mode != MODE_RESIDUAL) return false;
-  if (a.mode == MODE_LINEARIZE) {  // standalone J^T J: J-level fp64 only, same layout rules as the step kernel
-    return a.J && a.ticket && a.G_out && a.c_out && a.n >= 2 && a.n <= 128 && !(a.n & 1) && a.J_row_major && a.J_ld == a.n && a.m_r > 0 &&
-           aligned16(a.J) && !(a.J_stride & 1) && a.G_out_ld >= a.n;
+  if (a.mode == MODE_LINEARIZE) {  // standalone J^T J: J-level fp64; packed J on the 16-byte stream, every other layout (odd n included) on the gather stream
+    return a.J && a.ticket && a.G_out && a.c_out && a.n >= 2 && a.n <= 128 && a.m_r > 0 && a.J_ld >= (a.J_row_major ? a.n : a.m_r) && a.G_out_ld >= a.n;
   }
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP && a.mode != MODE_RESIDUAL) return false;
   if (a.mode == MODE_RESIDUAL && !a.r_out) return false;
@@ -2083,7 +2083,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
       (a.m > 128 || (a.m > 64 && a.n > 64 && a.mode != MODE_STEP)))
     return launch_fused_mc4(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && a.k > 15) return launch_fused_ny2(a, num_cus, stream);
-  if (a.mode != MODE_LINEARIZE && fused_needs_gather(a)) return launch_fused_gather(a, num_cus, stream);
+  if (fused_needs_gather(a) || (a.mode == MODE_LINEARIZE && (a.n & 1))) return launch_fused_gather(a, num_cus, stream);
 #endif
   if (a.mode == MODE_LINEARIZE) {
     const int wl = a.n > 96 ? 1 : (a.n > 64 ? 2 : 3);

@@ -16,6 +16,15 @@ hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t str
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
   const dim3 gd((unsigned)grid), bd(256 * wps);
+  if (a.mode == MODE_LINEARIZE) {  // mo_linearize / mo_fill_qp with column-major, strided, unaligned J or odd n
+    switch (grid_tile) {
+      case 2: hipLaunchKernelGGL((kkt_fused_linearize_kernel<2, 3, JMODE_GATHER>), gd, bd, 0, stream, a); break;
+      case 4: hipLaunchKernelGGL((kkt_fused_linearize_kernel<4, 3, JMODE_GATHER>), gd, bd, 0, stream, a); break;
+      case 6: hipLaunchKernelGGL((kkt_fused_linearize_kernel<6, 2, JMODE_GATHER>), gd, bd, 0, stream, a); break;
+      default: hipLaunchKernelGGL((kkt_fused_linearize_kernel<8, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;
+    }
+    return hipGetLastError();
+  }
   if (solve) {
     switch (grid_tile) {
       case 2: hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, false, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;

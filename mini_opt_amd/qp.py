@@ -360,7 +360,7 @@ def linearize(problem: BatchedQP, force_generic: bool = False):
         G = torch.empty(B, n, n, dtype=ref.dtype, device=ref.device)
         c = torch.empty(B, n, dtype=ref.dtype, device=ref.device)
         f = torch.empty(B, dtype=ref.dtype, device=ref.device)
-        q = BatchedQP(n=n, J=problem.J, r=problem.r, lam=problem.lam)
+        q = BatchedQP(n=n, J=problem.J, r=problem.r, lam=problem.lam, J_layout=problem.J_layout, J_rows=problem.J_rows)
         prob = q.as_struct()
         L.check(lib.mo_linearize(plan, C.byref(prob), B, _ptr(G), n * n, n, _ptr(c), n, _ptr(f), _stream()))
     finally:

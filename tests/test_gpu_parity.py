@@ -730,6 +730,34 @@ def test_fused_f32_solve_iterate_residual(n, k, m, m_r, level):
     assert s.solve_kernel().startswith("fused_solve"), s.solve_kernel()
 
 
+@pytest.mark.parametrize("n,m_r", [(63, 131), (33, 40), (7, 9), (64, 128), (101, 150), (128, 64), (40, 37)])
+@pytest.mark.parametrize("layout", ["packed", "col", "rowld", "unaligned"])
+def test_fused_linearize_takes_every_layout_of_J(n, m_r, layout):
+    """mo_linearize in fp64 on the fused kernels for every layout of J the C ABI accepts and for odd n (the gather stream): G = J^T J + lambda I
+    (lower triangle, strict upper exactly zero), c = J^T r, 0.5 |r|^2 against the dense products, and bit-compatible with the generic kernel's tolerance."""
+    rng = np.random.default_rng(n * 3 + m_r)
+    B = 7
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    lam = 0.125
+    kw = {}
+    if layout == "packed":
+        Jt = T(J)
+    elif layout == "rowld":
+        wide = np.full((B, m_r, n + 3), 7.7); wide[:, :, :n] = J; Jt = T(wide)
+    elif layout == "col":
+        colw = np.full((B, n, m_r + 2), -7.7); colw[:, :, :m_r] = J.transpose(0, 2, 1); Jt = T(colw); kw = dict(J_layout="col", J_rows=m_r)
+    else:
+        flat = torch.zeros(B * m_r * n + 1, dtype=torch.float64, device="cuda:0"); flat[1:] = T(J).reshape(-1); Jt = flat[1:].view(B, m_r, n)
+    prob = Q.BatchedQP(n=n, k=0, m=0, J=Jt, r=T(r), lam=lam, **kw)
+    G, c, half = Q.linearize(prob)
+    Gn = G.cpu().numpy().transpose(0, 2, 1)
+    ref = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+    assert np.all(np.triu(Gn, 1) == 0.0)
+    np.testing.assert_allclose(np.tril(Gn), np.tril(ref), rtol=0, atol=1e-12 * m_r)
+    np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=0, atol=1e-12 * m_r)
+    np.testing.assert_allclose(half.cpu().numpy(), 0.5 * np.einsum("bq,bq->b", r, r), rtol=1e-13)
+
+
 @pytest.mark.parametrize("n,m_r", [(128, 256), (64, 128), (128, 4), (64, 260)])
 def test_fused_f32_linearize(n, m_r):
     """mo_linearize in fp32 on the fused kernel: G = J^T J + lambda I (lower triangle; strict upper exactly zero, residual.hpp:216-220),
