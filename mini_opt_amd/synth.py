@@ -113,6 +113,8 @@ def make_batch_torch(n: int, k: int, m: int, m_r: int, batch: int, device, dtype
         return torch.rand(*shape, generator=g, device=device, dtype=torch.float64) * (hi - lo) + lo
 
     h = m // 2
+    if h > n or (m & 1):  # a lower and an upper bound on each of m / 2 DISTINCT variables; checked here, on the host, not by an out-of-range gather on the device
+        raise ValueError(f"synthetic batches need an even m <= 2 n (got n = {n}, m = {m})")
     J = torch.empty(batch, m_r, n, device=device, dtype=dtype)
     step = max(1, (1 << 27) // max(1, m_r * n))  # generate in slices to bound the fp64 temporary
     for b0 in range(0, batch, step):
