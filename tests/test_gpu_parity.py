@@ -782,7 +782,7 @@ def test_fused_f32_linearize(n, m_r):
     np.testing.assert_allclose(half.cpu().numpy(), halfg.cpu().numpy(), rtol=2e-6)
 
 
-@pytest.mark.parametrize("which", ["f32_cfg4", "f64_two_y_tiles"])
+@pytest.mark.parametrize("which", ["f32_cfg4", "f64_two_y_tiles", "f64_one_tile", "f64_four_slots"])
 @pytest.mark.parametrize("batch", [1, 12])
 def test_status_words_of_the_new_solve_kernels(which, batch):
     """The failure channels of the reference (F_ASSERT s > 0 qp.cc:285, constraint index qp.cc:70-72, FailedFactorization / a NaN
@@ -790,8 +790,12 @@ def test_status_words_of_the_new_solve_kernels(which, batch):
     step, the healthy problems untouched; batch = 1 exercises the ticket loop with fewer problems than waves."""
     if which == "f32_cfg4":
         d = synth.CONFIGS["cfg4"]; n, k, m, m_r, dt = d["n"], d["k"], d["m"], d["m_r"], torch.float32
-    else:
+    elif which == "f64_two_y_tiles":
         n, k, m, m_r, dt = 64, 24, 40, 128, torch.float64
+    elif which == "f64_one_tile":
+        n, k, m, m_r, dt = 8, 2, 4, 16, torch.float64          # BASELINE configs[0]: kkt_fused_tiny.hip
+    else:
+        n, k, m, m_r, dt = 96, 6, 160, 192, torch.float64      # kkt_fused_mc4.hip
     hb = synth.make_batch(n, k, m, m_r, 12, stream=5)
     hb.vars[1, n] = 0.0                 # s = 0
     hb.cons_var[4, 0] = n + 7           # index beyond n
