@@ -48,10 +48,53 @@ def test_two_ranks_weak_scaling_config():
     assert "configs[2]" in out["config"]["workload"]
 
 
-def test_gpus_without_launcher_is_an_error():
+def _clean_env(**extra):
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def test_bare_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (what the driver types for the scaling run): the parent spawns the ranks as child
+    processes and relays rank 0's one JSON line."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry"],
+                         cwd=ROOT, env=_clean_env(MO_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout     # stdout carries the JSON line and nothing else
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry"] is True
+    assert out["config"]["name"] == "cfg5" and out["config"]["batch_total"] == 2 ** 20 and out["config"]["batch_per_gpu"] == 2 ** 19
+    assert out["units_per_step_all_ranks"] == 2 ** 20
+
+
+def test_the_launching_parent_never_touches_torch():
+    """The parent of a bare `--gpus N` run must not initialise HIP: it does not even import torch (checked through an import hook that
+    only the parent process sees -- the ranks are started with a clean interpreter)."""
+    code = ("import sys, runpy\n"
+            "class Block:\n"
+            "    def find_spec(self, name, path=None, target=None):\n"
+            "        if name == 'torch' or name.startswith('torch.'):\n"
+            "            raise ImportError('the launching parent imported ' + name)\n"
+            "sys.meta_path.insert(0, Block())\n"
+            f"sys.argv = [{os.path.join(ROOT, 'bench.py')!r}, '--gpus', '2', '--steps', '2', '--warmup', '0', '--dry']\n"
+            f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(MO_BENCH_BACKEND="gloo"), capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 2
+
+
+def test_a_failing_rank_fails_the_bare_run():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry"],
+                         cwd=ROOT, env=_clean_env(MO_BENCH_BACKEND="no-such-backend"), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_that_disagrees_with_gpus_is_an_error():
+    env = _clean_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry"], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and "WORLD_SIZE" in res.stderr

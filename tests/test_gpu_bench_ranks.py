@@ -38,3 +38,21 @@ def test_two_ranks_on_one_gpu_run_config5_shards():
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 32768) < 1e-3 * 32768  # value = units of all ranks / max time
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
     assert out["status_ok"] == out["status_total"]
+
+
+def test_bare_gpus_flag_runs_two_real_ranks():
+    """The driver's scaling command is a bare `python bench.py --gpus N`: the parent (which never touches the GPU) starts the ranks as child
+    processes and relays rank 0's line.  Here N = 2 on the box's one GPU with gloo standing in for RCCL."""
+    env = dict(os.environ, MO_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "cfg5",
+           "--batch", "16384", "--no-cpu-baseline", "--sustain-seconds", "0.3"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["batch_total"] == 32768 and out["config"]["kernel"] == "fused_mfma_f64_n64"
+    assert out["value"] > 1e6 and out["status_ok"] == out["status_total"]
+    assert out["sustained"]["seconds"] >= 0.3 and out["sustained"]["value"] > 1e6
