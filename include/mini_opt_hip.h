@@ -310,6 +310,10 @@ typedef int (*mo_nls_eval_fn)(void* user, int32_t what, void* stream);  /* non-z
 #define MO_NLS_ITER_RECORD(max_line_search_iterations) (MO_NLS_ITER_HEADER + 3 * ((max_line_search_iterations) + 1))
 
 void mo_default_nls_params(mo_nls_params* params);
+/* 1 when mo_nls_solve takes QPNullSpaceSolver's path for this plan's shape (equalities, no inequalities: nonlinear.cc:83-86 -- and the
+ * shape fits the null-space kernel), 0 when its QPs go through the interior-point Solve: tells which record layout `iterations` carries
+ * (NLSIteration::qp_outputs / qp_term_state, structs.hpp:277-326). */
+int mo_plan_nls_uses_nullspace(const mo_plan* plan);
 /* termination [batch] (mo_nls_termination), num_iterations [batch], iterations [batch][max_iterations][MO_NLS_ITER_RECORD]
  * (may be NULL), status [batch] (may be NULL).  Synchronises `stream` (one small read-back per outer iteration and per
  * line-search step to learn whether any problem is still active). */

@@ -24,7 +24,7 @@ MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
 
 # every symbol include/mini_opt_hip.h declares
 EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
-           "mo_plan_destroy", "mo_plan_step_kernel", "mo_plan_solve_kernel", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
+           "mo_plan_destroy", "mo_plan_step_kernel", "mo_plan_solve_kernel", "mo_plan_nls_uses_nullspace", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
            "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative",
            "mo_default_nls_params", "mo_nls_solve", "mo_nullspace_solve", "mo_residual_eval"]
 
@@ -120,6 +120,8 @@ def lib() -> C.CDLL:
     L.mo_plan_step_kernel.restype = C.c_char_p
     L.mo_plan_solve_kernel.argtypes = [vp, C.POINTER(Problem)]
     L.mo_plan_solve_kernel.restype = C.c_char_p
+    L.mo_plan_nls_uses_nullspace.argtypes = [vp]
+    L.mo_plan_nls_uses_nullspace.restype = C.c_int
     L.mo_linearize.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, i32, vp, i64, vp, vp]
     L.mo_kkt_residual.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, u32, vp, i64, vp, vp]
     L.mo_newton_step.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, i64, dbl, u32, vp, i64, vp, vp, vp]

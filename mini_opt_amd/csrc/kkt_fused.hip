@@ -1386,7 +1386,18 @@ template <int NT, int WPS, int MC = 1, int NY = 1> struct SolveCfg {
   static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
   static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);
   static_assert(D >= 2, "LDS budget");
-  static constexpr int LDS = D * SLOT + VEC;
+  // Tile park: G = J^T J + lambda I and c do not change between the passes of one Solve.  After the first pass has streamed J the ring
+  // is idle for the rest of the problem, so its bytes (and whatever else the wave's share of the 160 KiB leaves) hold the G tiles
+  // lane-linearly -- PARK_LDS of the NTILES tiles; the rest goes to a global scratch indexed by the wave's SLOT in the persistent grid
+  // (a few KB per wave that stay in L2), not by problem.  Nothing of a cached pass then comes from HBM.
+  static constexpr int NTILES = NT * (NT + 1) / 2;
+  static constexpr int BUDGET = ((160 * 1024) / (4 * WPS)) & ~15;
+  static constexpr int PARK_FIT = (BUDGET - VEC - N * 8) / 2048;
+  static constexpr int PARK_LDS = PARK_FIT > NTILES ? NTILES : PARK_FIT;
+  static constexpr int PARK_GLOBAL = NTILES - PARK_LDS;
+  static constexpr int AREA = D * SLOT > PARK_LDS * 2048 + N * 8 ? D * SLOT : PARK_LDS * 2048 + N * 8;  // ring, later the parked tiles + c
+  static constexpr int LDS = AREA + VEC;
+  static_assert(PARK_LDS >= 0 && LDS <= BUDGET, "LDS budget");
 };
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
@@ -1401,7 +1412,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   char* const smem = smem_all + wave * C::LDS;
-  double* const xs = reinterpret_cast<double*>(smem + D * SLOT);  // x, natural order
+  double* const xs = reinterpret_cast<double*>(smem + C::AREA);  // x, natural order
   double* const xp = xs + N;                                      // x, permuted order
   double* const azS = xp + N;                                     // sum a z per variable, natural order
   double* const diagS = azS + N;                                  // barrier diagonal per variable
@@ -1565,9 +1576,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     // G = J^T J + lambda I and c = J^T r do not change between the passes of one Solve: the first pass parks its tiles in a per-problem
     // scratch (plan-owned, a.G_out; lane-linear, every lane reads back exactly what it wrote), later passes reload 22 KB instead of
     // re-streaming 64 KB of J and redoing 320 of the 440 MFMAs (n = 64 figures).
-    constexpr int NTILES = NT * (NT + 1) / 2, TILE_SCRATCH = NTILES * 256 + NT * 64;
-    double* const Gt = (!QPL && a.G_out) ? (double*)a.G_out + (size_t)p * TILE_SCRATCH : nullptr;
+    constexpr int PARK_LDS = C::PARK_LDS, PARK_GLOBAL = C::PARK_GLOBAL;
+    double* const park = reinterpret_cast<double*>(smem);             // PARK_LDS tiles (256 doubles each, lane-linear), then c (V16, N doubles)
+    double* const cpark = park + PARK_LDS * 256;
+    // the tiles that do not fit: global scratch of this wave's slot in the persistent grid (plan-owned; NULL: re-stream / re-load every pass)
+    double* const Gt = (PARK_GLOBAL > 0 && a.G_out) ? (double*)a.G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)a.G_out_stride : nullptr;
+    const bool can_park = PARK_GLOBAL == 0 || Gt != nullptr;
     bool tiles_cached = false;
+    // Lanes whose J piece lies beyond the row never receive DMA data and must read zeros from the ring: a problem that parked tiles there
+    // leaves it dirty, so streams that rely on the zeros (n below the grid, flat / gather pieces) clear it again first.
+    if (!QPL && (JMODE != JMODE_VECTOR || nn != N)) {
+      for (int i = lane; i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
+      lds_fence();
+    }
     double mu_used = mu;   // the mu handed to the previous Iterate
     double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
     // Mehrotra predictor-corrector (qp.cc:170-187): solve with mu = 0, probe alpha(tau = 1), then solve again with the second-order
@@ -1582,7 +1603,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       JStream<NT, D, JMODE, NY> stream;
-      const bool stream_now = !QPL && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;  // wave-uniform, and hipcc must know it
+      const bool build_now = __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;          // wave-uniform, and hipcc must know it
+      const bool stream_now = !QPL && build_now;
       if (stream_now) {
         stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
         stream.prologue();
@@ -1605,7 +1627,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0;
       }
       double cvec[NT];
-      if (QPL) {
+      if (QPL && build_now) {
         load_g_tiles<NT, NY>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, nn, g, j, U, cvec);
       } else if (stream_now) {
         double cpart[NT];
@@ -1619,26 +1641,34 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
-        if (Gt) {  // park the tiles and c for the following passes
-          int ti = 0;
-#pragma unroll
-          for (int ta = 0; ta < NT; ++ta) {
-#pragma unroll
-            for (int tb = ta; tb < NT; ++tb, ++ti) *(d4*)(Gt + ((size_t)ti * 64 + lane) * 4) = U[ta * NB + tb];
-          }
-#pragma unroll
-          for (int c = 0; c < NT; ++c) Gt[NTILES * 256 + c * 64 + lane] = cvec[c];
-          tiles_cached = true;
-        }
-      } else {  // reload what the first pass parked
+      } else {  // fetch what the first pass parked
         int ti = 0;
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
-          for (int tb = ta; tb < NT; ++tb, ++ti) U[ta * NB + tb] = *(const d4*)(Gt + ((size_t)ti * 64 + lane) * 4);
+          for (int tb = ta; tb < NT; ++tb, ++ti) {
+            if (ti < PARK_LDS) U[ta * NB + tb] = *(const d4*)(park + (ti * 64 + lane) * 4);
+            else U[ta * NB + tb] = *(const d4*)(Gt + ((size_t)(ti - PARK_LDS) * 64 + lane) * 4);
+          }
         }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) cvec[c] = Gt[NTILES * 256 + c * 64 + lane];
+        for (int c = 0; c < NT; ++c) cvec[c] = cpark[16 * c + j];
+      }
+      if (build_now && can_park && !iterate_mode) {  // park the tiles and c for the following passes (the stream has drained: the ring is free)
+        int ti = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) {
+#pragma unroll
+          for (int tb = ta; tb < NT; ++tb, ++ti) {
+            if (ti < PARK_LDS) *(d4*)(park + (ti * 64 + lane) * 4) = U[ta * NB + tb];
+            else *(d4*)(Gt + ((size_t)(ti - PARK_LDS) * 64 + lane) * 4) = U[ta * NB + tb];
+          }
+        }
+        if (g == 0) {
+#pragma unroll
+          for (int c = 0; c < NT; ++c) cpark[16 * c + j] = cvec[c];
+        }
+        tiles_cached = true;
       }
       {  // unit diagonal for the padding variables (index >= nn): they stay at zero
         double padv[NT];

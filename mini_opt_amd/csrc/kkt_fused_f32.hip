@@ -675,7 +675,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     // G = J^T J + lambda I and c = J^T r do not change between the passes: the first pass parks its tiles in a per-problem scratch
     // (plan-owned, a.G_out; lane-linear), later passes reload them instead of re-streaming J
     constexpr int NTILES = NT * (NT + 1) / 2, TILE_SCRATCH = NTILES * 256 + NT * 64;
-    float* const Gt = (!qpl && a.G_out) ? (float*)a.G_out + (size_t)p * TILE_SCRATCH : nullptr;
+    // (indexed by the wave's slot in the persistent grid, not by problem: 2 048 slots x 38 KB stay in the last-level cache)
+    float* const Gt = (!qpl && a.G_out) ? (float*)a.G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)a.G_out_stride : nullptr;
+    static_assert(TILE_SCRATCH <= (NT * (NT + 1) / 2) * 256 + NT * 64, "mo_api.hip sizes a slot with this formula");
     bool tiles_cached = false;
     float mu_used = mu;
     float ip_alpha_p = 1.0f, ip_alpha_d = 1.0f;

@@ -45,6 +45,21 @@ namespace {
 // Every stage is inlined into its kernel: with R = 9 / 12 hipcc otherwise keeps assemble_and_factor (two call sites in MODE_SOLVE) as a real
 // function, and the kernel that called it returned alpha_dual = 1 for every problem -- the records a caller reads after the call were lost.
 #define MO_INLINE __attribute__((always_inline))
+// Diagnostic builds only (tools/alpha_dual_probe/): MO_GENERIC_PROBE_CALL keeps assemble_and_factor a real function again, MO_GENERIC_PROBE
+// makes Iterate / Solve report what compute_alpha saw (z[0], dz[0], the dual step length in LDS) in the three record slots a
+// COMPLEMENTARITY iteration leaves NaN.  The product build defines neither.
+#if defined(MO_GENERIC_PROBE_CALL)
+#define MO_INLINE_FACTOR __attribute__((noinline))
+#elif defined(MO_GENERIC_PROBE_AUTO)
+#define MO_INLINE_FACTOR            /* the inliner's own choice, as before commit a1d56f0 */
+#else
+#define MO_INLINE_FACTOR MO_INLINE
+#endif
+#ifdef MO_GENERIC_PROBE_BYVAL
+#define MO_FACTOR_WS(T) const Ws<T>     /* the workspace descriptor by value (registers) instead of by reference (the caller's scratch) */
+#else
+#define MO_FACTOR_WS(T) const Ws<T>&
+#endif
 
 #ifdef MO_GENERIC_STAMPS
 __device__ unsigned long long g_nd_stamps[8];   // diagnostic build only: where newton_direction spends its time
@@ -395,7 +410,7 @@ __device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
 
 // Reduced-KKT assembly (Sigma on the diagonal, qp.cc:293-298) + LDL^T.  Returns MO_STATUS_*.
 template <typename T, int TG, int R>
-__device__ MO_INLINE int assemble_and_factor(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+__device__ MO_INLINE_FACTOR int assemble_and_factor(MO_FACTOR_WS(T) w, int n, int k, int m, bool include_ineq, int tid) {
   const int P = n + k;
   if (include_ineq) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
@@ -528,6 +543,11 @@ __device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T
   unsigned long long nd_prev = __builtin_amdgcn_s_memtime();
 #endif
   const int st = assemble_and_factor<T, TG, R>(w, n, k, m, true, tid);
+#ifdef MO_GENERIC_PROBE_FENCE
+  __threadfence_block();
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+#endif
   MO_NDSTAMP(0);
   if (st != MO_STATUS_OK) return st;
   if (m == 0) {
@@ -551,6 +571,9 @@ __device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T
   if (m > 0) {                                                                    // :191-193
     compute_alpha(w, n, k, m, tau, tid);
     ip[1] = w.red[5]; ip[2] = w.red[6];
+#ifdef MO_GENERIC_PROBE
+    if (strategy != MO_PREDICTOR_CORRECTOR) { ip[3] = w.vars[n + m + k]; ip[4] = w.delta[n + m + k]; ip[5] = w.red[6]; }
+#endif
   }
   return MO_STATUS_OK;
 }
@@ -884,8 +907,11 @@ __global__ __launch_bounds__(kMaxThreads) void nullspace_kernel(const KernelArgs
     for (int q = tid; q < k; q += kThreads) w.beq[q] = bp[q];
     if (j_level) {
       const T lam = a.lambda_vec ? ((const T*)a.lambda_vec)[p * a.lambda_vec_stride] : (T)a.lambda;
+      // the register tiling of J^T J covers n <= TG R columns: 8 x 6 for single-wave workgroups (n + k <= 48), 16 x 9 up to n = 144 and
+      // 16 x 12 beyond (only fp32 plans get there: n = 145 ... 192 still fits the LDS in fp32, in fp64 n <= 128 does)
       if (kThreads == 64) accumulate_jtj<T, 8, 6>(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
-      else accumulate_jtj<T, 16, 9>(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
+      else if (n <= 144) accumulate_jtj<T, 16, 9>(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
+      else if constexpr (sizeof(T) == 4) accumulate_jtj<T, 16, 12>(w, n, m_r, (const T*)a.J + p * a.J_stride, a.J_ld, a.J_row_major, (const T*)a.r + p * a.r_stride, lam, tid);
     }
     for (int l = wave; l < n; l += kWaves)   // selfadjointView<Lower>: mirror the lower triangle
       for (int i = lane; i < l; i += 64) op.G(i, l) = op.G(l, i);
@@ -1118,6 +1144,7 @@ hipError_t launch_nullspace(const KernelArgs& a, int dtype, int num_cus, hipStre
   KernelArgs b = a;
   b.m = 0;
   const size_t lds = nullspace_lds_bytes(a.n, a.k, a.m_r, elem);
+  if (a.J && a.n > (dtype == MO_F64 ? 144 : 192)) return hipErrorInvalidValue;  // beyond the J^T J register tiling (mo_plan_create's n + k <= 192 keeps fp32 inside)
   const int threads = (a.n + a.k <= 48) ? 64 : kMaxThreads;
   const int max_per_cu = 32 / (threads / 64);
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));

@@ -39,7 +39,7 @@ struct mo_plan {
   // scratch for mo_qp_solve with J-level input: G [max_batch][n*n], c [max_batch][n]
   void* G_scratch;
   void* c_scratch;
-  void* tile_scratch;  // fused Solve with J-level input: the G tiles + c of every problem between passes
+  void* tile_scratch;  // fused Solve: per wave slot of the persistent grid, the G tiles a wave cannot park in LDS between passes
   unsigned long long* ticket;  // device work counter of the fused kernels (zeroed on the stream before each launch)
 };
 
@@ -471,17 +471,21 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
     a.G_out = plan->G_scratch; a.G_out_stride = (long long)(n * n); a.G_out_ld = (int)n;
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
   }
-  if (a.J && use_fused && batch <= plan->desc.max_batch) {  // tile cache between the passes (optional: without it J is re-streamed)
+  if (use_fused) {
+    // Tile park of the fused Solve kernels: the G tiles a wave cannot keep in LDS between the passes go to a scratch indexed by the
+    // wave's slot in the persistent grid (one workgroup per CU, at most twelve waves each), so its size does not depend on the batch
+    // and the lines a wave re-reads every pass stay in its XCD's L2.  Optional: without it the kernel rebuilds the tiles every pass.
     const int nt = plan->desc.n > 96 ? 8 : plan->desc.n > 64 ? 6 : plan->desc.n > 32 ? 4 : 2;
-    const size_t per_problem = (size_t)(nt * (nt + 1) / 2) * 256 + (size_t)nt * 64;
+    const size_t per_slot = (size_t)(nt * (nt + 1) / 2) * 256 + (size_t)nt * 64;
+    const size_t slots = (size_t)plan->num_cus * 12;
     MO_HIP_CHECK(hipSetDevice(plan->desc.device));
     if (!plan->tile_scratch) {
-      if (hipMalloc(&plan->tile_scratch, (size_t)plan->desc.max_batch * per_problem * plan->elem) != hipSuccess) {
-        plan->tile_scratch = nullptr;  // not fatal: the kernel re-streams J instead
+      if (hipMalloc(&plan->tile_scratch, slots * per_slot * plan->elem) != hipSuccess) {
+        plan->tile_scratch = nullptr;
         (void)hipGetLastError();
       }
     }
-    a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_problem;
+    a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_slot;
   }
   return launch_chosen(plan, a, choice, stream);  // fused Solve kernel (fp64: n <= 128; fp32: n = 64 / 128), generic kernel otherwise
 }
@@ -545,6 +549,13 @@ void mo_default_nls_params(mo_nls_params* p) {
   p->retraction = MO_RETRACT_EUCLIDEAN;
 }
 
+
+static bool nls_takes_nullspace_path(const mo_plan* plan) {
+  const mo_plan_desc& d = plan->desc;
+  return d.m == 0 && d.k > 0 && d.k <= d.n && mo::nullspace_lds_bytes(d.n, d.k, d.m_r, plan->elem) <= 160 * 1024;
+}
+
+int mo_plan_nls_uses_nullspace(const mo_plan* plan) { return plan && nls_takes_nullspace_path(plan) ? 1 : 0; }
 
 int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const mo_nls_params* prm, mo_nls_eval_fn eval,
                  void* user, int32_t* termination, int32_t* num_iterations, void* iterations, int32_t* status, void* stream) {
@@ -684,7 +695,7 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
     MO_HIP_CHECK(mo::launch_nonlinear_errors(ea, d.dtype, s));
     if (m > 0) MO_HIP_CHECK(mo::launch_shift_constraints(sa, d.dtype, s));
     // ComputeStepDirection (nonlinear.cc:216-247): the interior-point QP on device
-    if (m == 0 && k > 0 && k <= n && mo::nullspace_lds_bytes(n, k, d.m_r, plan->elem) <= 160 * 1024) {
+    if (nls_takes_nullspace_path(plan)) {
       // equality constraints only: QPNullSpaceSolver (nonlinear.cc:83-86, 249-258) -- singular G = J^T J is fine as long as
       // the reduced Hessian is positive definite; NOT_POSITIVE_DEFINITE ends the problem with QP_INDEFINITE (:103-105)
       mo_plan tmp = *plan;

@@ -344,7 +344,7 @@ class ConstrainedNonlinearLeastSquares:
                 prob.qp_lagrange = _ptr(qp_lag)
         self._callback_error = None
         self._iter_done = 0
-        null_path = self.m == 0 and self.k > 0
+        null_path = bool(L.lib().mo_plan_nls_uses_nullspace(self._plan.h))   # the C side's own predicate (shape AND kernel capacity)
         self._outputs_view = NLSSolverOutputs(term, nit, its, status, qp_its, qp_lag, null_path)
         cb = L.NLS_EVAL_FN(self._eval)
         rc = L.lib().mo_nls_solve(self._plan.h, C.byref(prob), B, C.byref(sp), cb, None, _ptr(term), _ptr(nit), _ptr(its),

@@ -201,11 +201,21 @@ class ConstrainedNonlinearLeastSquares:
     nonlinear.cc:160-168; default x + alpha dx); `user_exit_callback(log) -> bool` is SetUserExitCallback (nonlinear.hpp:157,
     nonlinear.cc:142-149): returning False ends the solve with USER_CALLBACK unless the iteration terminates anyway."""
 
-    def __init__(self, problem: Problem, retraction=None, user_exit_callback=None):
+    def __init__(self, problem: Problem, retraction=None, user_exit_callback=None, track_margins=False):
         self.p = problem
         self.variables = np.zeros(problem.dimension)
         self.retraction = retraction
         self.user_exit_callback = user_exit_callback
+        # Decision margins (oracle/margins.py has the rule they serve): with track_margins every branch of the outer loop logs
+        # (outer iteration, name, relative distance of the deciding quantity from its threshold) into self.margins; the inner
+        # interior-point solves log the smallest margin of their own run under the name "qp".
+        self.track_margins = track_margins
+        self.margins: List[Tuple[int, str, float]] = []
+        self._iter = 0
+
+    def _note(self, name, margin):
+        if self.track_margins:
+            self.margins.append((self._iter, name, float(margin)))
 
     def compute_step_direction(self, qp: QPData, params: Params):
         """nonlinear.cc:216-258.  Returns (dx, lagrange_linf | None, indefinite, n_qp_iterations)."""
@@ -221,8 +231,12 @@ class ConstrainedNonlinearLeastSquares:
                     cons_b=np.array([c[2] for c in qp.constraints], float))
         s = orc.Solver(oq)
         guess = orc.GUESS_SOLVE_EQUALITY_CONSTRAINED if k > 0 else orc.GUESS_NAIVE
-        _, its = s.solve(max_iterations=params.max_qp_iterations, termination_kkt_tol=params.termination_kkt_tolerance,
-                         initial_mu=1.0, sigma=0.1, initialize_mu_with_complementarity=0, initial_guess_method=guess)
+        qp_kw = dict(max_iterations=params.max_qp_iterations, termination_kkt_tol=params.termination_kkt_tolerance,
+                     initial_mu=1.0, sigma=0.1, initialize_mu_with_complementarity=0, initial_guess_method=guess)
+        _, its = s.solve(**qp_kw)
+        if self.track_margins:
+            from . import margins as _margins
+            self._note("qp", _margins.min_margin(_margins.solve_with_margins(oq, **qp_kw)[3])[0])
         x, _, y, _ = s.blocks(s.variables)
         linf = float(np.max(np.abs(y))) if k > 0 else None  # qp.cc:539-546
         return x.copy(), linf, False, len(its)
@@ -245,6 +259,8 @@ class ConstrainedNonlinearLeastSquares:
                         ab = cubic_approx_coeffs(errors_pre.total(penalty), directional, a0, e0.total(penalty), a1,
                                                  e1.total(penalty))
                         new_alpha = cubic_approx_minimum(directional, ab)
+                    if new_alpha is not None and math.isfinite(new_alpha):
+                        self._note("alpha_valid", min(abs(new_alpha), abs(new_alpha - alpha)) / alpha)
                     if new_alpha is None or not math.isfinite(new_alpha) or new_alpha <= 0.0 or new_alpha >= alpha:
                         return STEP_FAILURE_INVALID_ALPHA, steps, candidate
                     alpha = new_alpha
@@ -258,11 +274,17 @@ class ConstrainedNonlinearLeastSquares:
             steps.append((alpha, e))
             if e.invalid():
                 return STEP_FAILURE_NON_FINITE_COST, steps, candidate
+            if it == 0:
+                self._note("first_order", abs(max(abs(d_f), abs(d_eq)) / params.absolute_first_derivative_tol - 1.0))
             if max(abs(d_f), abs(d_eq)) < params.absolute_first_derivative_tol:
                 return STEP_FIRST_ORDER_SATISFIED, steps, candidate
+            if it == 0:
+                self._note("derivative_sign", abs(directional) / max(abs(d_f), abs(penalty * d_eq), 1e-300))
             if directional > 0:
                 return STEP_POSITIVE_DERIVATIVE, steps, candidate
-            if e.total(penalty) <= errors_pre.total(penalty) + directional * alpha * armijo_c1:
+            armijo_rhs = errors_pre.total(penalty) + directional * alpha * armijo_c1
+            self._note("armijo", abs(e.total(penalty) - armijo_rhs) / max(abs(errors_pre.total(penalty)), 1e-300))
+            if e.total(penalty) <= armijo_rhs:
                 return STEP_SUCCESS, steps, candidate
         return STEP_MAX_ITERATIONS, steps, candidate
 
@@ -274,7 +296,9 @@ class ConstrainedNonlinearLeastSquares:
         penalty = params.equality_penalty_initial
         logs: List[IterationLog] = []
         has_eq = self.p.equality is not None
-        for _ in range(params.max_iterations):
+        self.margins = []
+        for outer in range(params.max_iterations):
+            self._iter = outer
             qp, errors_pre = linearize_and_fill_qp(self.variables, lam, self.p)
             dx, linf, indefinite, n_qp = self.compute_step_direction(qp, params)
             if indefinite:
@@ -282,6 +306,7 @@ class ConstrainedNonlinearLeastSquares:
             d_f, d_eq = compute_qp_cost_derivative(qp, dx)
             if has_eq:
                 new_penalty = select_penalty(qp, dx, linf, params.equality_penalty_rho)
+                self._note("penalty", abs(new_penalty - penalty) / max(abs(penalty), 1e-300))
                 if new_penalty > penalty:
                     penalty = new_penalty * params.equality_penalty_scale_factor
             step_result, steps, candidate = self.select_step_size(params, errors_pre, d_f, d_eq, penalty, dx)
@@ -296,10 +321,14 @@ class ConstrainedNonlinearLeastSquares:
                     lam = max(lam * params.lambda_decrease_on_success, params.min_lambda)
                 state = NOMINAL
                 final = steps[-1][1]
+                self._note("absolute_exit", abs(final.linf() / params.absolute_exit_tol - 1.0))
                 if final.linf() < params.absolute_exit_tol:
                     exit_state = SATISFIED_ABSOLUTE_TOL
-                elif final.total(penalty) > errors_pre.total(penalty) * (1 - params.relative_exit_tol):
-                    exit_state = SATISFIED_RELATIVE_TOL
+                else:
+                    rel_rhs = errors_pre.total(penalty) * (1 - params.relative_exit_tol)
+                    self._note("relative_exit", abs(final.total(penalty) - rel_rhs) / max(abs(rel_rhs), 1e-300))
+                    if final.total(penalty) > rel_rhs:
+                        exit_state = SATISFIED_RELATIVE_TOL
             elif step_result == STEP_FIRST_ORDER_SATISFIED:
                 exit_state = SATISFIED_FIRST_ORDER_TOL
             elif step_result in (STEP_MAX_ITERATIONS, STEP_POSITIVE_DERIVATIVE):
@@ -308,6 +337,7 @@ class ConstrainedNonlinearLeastSquares:
                     state = ATTEMPTING_RESTORE_LM
                 else:
                     lam *= 10.0
+                self._note("max_lambda", abs(lam / params.max_lambda - 1.0) if params.max_lambda > 0 else 1.0)
                 if lam > params.max_lambda:
                     exit_state = MAX_LAMBDA
             logs.append(IterationLog(old_lam, errors_pre, d_f, d_eq, penalty, step_result, steps, n_qp, state))

@@ -58,8 +58,9 @@ def test_random_shapes_and_layouts(seed):
         sg = Q.QPInteriorPointSolver(Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=lam, A_eq=T(A) if k else None, b_eq=T(b) if k else None,
                            cons_var=T(cv, torch.int32) if m else None, cons_a=T(ca) if m else None, cons_b=T(cb) if m else None))
         og = sg.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=10, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
-        same = (out.num_iterations == og.num_iterations) & (out.termination_state == og.termination_state)
-        assert same.float().mean() >= 0.8, (n, k, m, m_r, which)
+        # every stream feeds the matrix cores the same operands in the same order: the layouts are bit-compatible, and so is the whole Solve
+        assert torch.equal(out.num_iterations, og.num_iterations) and torch.equal(out.termination_state, og.termination_state), (n, k, m, m_r, which)
+        assert torch.equal(s.variables(), sg.variables()), (n, k, m, m_r, which)
 
 
 @pytest.mark.parametrize("seed", [11, 12] + EXTRA_SEEDS)
@@ -69,13 +70,15 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
     probe step lengths, mu_affine) and the state after it, and for Solve the termination state, the iteration count and the optimum.
     Problems are built around a strictly feasible point with small margins so that some inequalities are active at the optimum."""
     rng = np.random.default_rng(seed)
+    from oracle import margins as M
     checked = {"fused": 0, "generic": 0}
-    strict = {"fused": 0, "generic": 0}
-    total = {"fused": 0, "generic": 0}
+    dis = {"fused": M.Disagreements(f"fuzz seed {seed}, fused Solve"), "generic": M.Disagreements(f"fuzz seed {seed}, generic Solve")}
     for trial in range(30):
         n = int(rng.integers(2, 129)); B = 4
-        # well-posed problems: at most n / 2 equalities and 2 n inequality entries.  (With k close to n or m >> n the start has slacks clamped at
-        # 1e-9, z = 1e9, and three correct implementations follow three different trajectories -- seen in a 40-seed soak of this test.)
+        # well-posed problems: at most n / 2 equalities and 2 n inequality entries.  (With k close to n or m >> n the start has slacks on the
+        # 1e-9 floor, z / s = 1e18, and the reduced KKT matrix is numerically singular: no double-precision formulation -- the reference's
+        # included -- gets the first step right there; tests/test_gpu_stress.py::test_first_step_from_an_overconstrained_naive_start measures
+        # every implementation against a long-double truth on exactly those shapes.)
         k = int(rng.integers(0, min(32, n // 2 + 1))); m = int(rng.integers(0, min(65, 2 * n + 1))); m_r = int(rng.integers(n, 2 * n + 8))
         level = rng.choice(["J", "QP"]); strategy = int(rng.integers(0, 3))
         J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
@@ -104,7 +107,7 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
             ref_it.append(([ip.mu, ip.alpha_primal, ip.alpha_dual, ip.alpha_probe_primal, ip.alpha_probe_dual, ip.mu_affine], o.variables.copy()))
             o2 = orc.Solver(qp)
             term, its = o2.solve(**kw)
-            ref_solve.append((term, len(its), o2.variables.copy()))
+            ref_solve.append((term, len(its), o2.variables.copy(), M.solve_with_margins(qp, **kw)[3]))
         tag = (seed, trial, level, n, k, m, m_r, strategy, guess)
         for family, force in (("fused", False), ("generic", True)):
             try:
@@ -127,16 +130,16 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
             assert torch.all(out.status == 0), (tag, family)
             tm = out.termination_state.cpu().numpy(); nit = out.num_iterations.cpu().numpy(); v = s.variables().cpu().numpy()
             for p in range(B):
-                # strict: the oracle's termination state after the oracle's iteration count.  Nearly determined problems (k close to n)
-                # sit on the tolerance for several iterations and may flip by one iteration with rounding: those must still be within one
-                # iteration and at the same point
-                strict[family] += int(tm[p] == ref_solve[p][0] and nit[p] == ref_solve[p][1])
-                total[family] += 1
-                assert abs(int(nit[p]) - ref_solve[p][1]) <= 2, (tag, family, p, tm, nit, [(t_, i_) for t_, i_, _ in ref_solve])
-                if tm[p] == Q.SATISFIED_KKT_TOL and ref_solve[p][0] == Q.SATISFIED_KKT_TOL:   # (a run that ends in MAX_ITERATIONS has no point to compare)
+                # The rule (oracle/margins.py): the oracle's termination state after the oracle's iteration count, unless a decision of the
+                # oracle's own run sat within rounding of its threshold (termination test, a step-length tie, the slack floor) -- a
+                # disagreement anywhere else fails.
+                same = bool(tm[p] == ref_solve[p][0] and nit[p] == ref_solve[p][1])
+                dis[family].check((tag, p, int(tm[p]), int(nit[p]), ref_solve[p][:2]), same, ref_solve[p][3] if not same else None)
+                if same and tm[p] == Q.SATISFIED_KKT_TOL:   # (a run that ends in MAX_ITERATIONS has no point to compare)
                     xs = max(1.0, np.abs(ref_solve[p][2][:n]).max())
                     assert np.abs(v[p][:n] - ref_solve[p][2][:n]).max() <= 1e-5 * xs, (tag, family, p)
             checked[family] += 1
     assert checked["fused"] == 30 and checked["generic"] >= 15, checked
     for family in ("fused", "generic"):
-        assert strict[family] >= 0.93 * total[family], (family, strict, total)
+        print(dis[family].report())
+        assert len(dis[family].items) <= 0.05 * dis[family].total, dis[family].report()

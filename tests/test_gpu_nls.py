@@ -70,6 +70,43 @@ def run_both(oprob, dprob, oparams, dparams, guesses):
     return out, dev_x, dev_term, dev_nit, np.array(ref_x), np.array(ref_term), np.array(ref_nit), ref_logs
 
 
+# Outer-loop decisions (Armijo test, exit tests, step-size validity ...) compare quantities the device and the oracle compute in a different
+# operation order: they may only disagree where the oracle's deciding quantity sat within NLS_KNIFE_EDGE (relative) of its threshold --
+# or where an inner interior-point solve itself sat on a knife edge (oracle/margins.py), after which the two runs continue from QP
+# solutions that differ at the level of the QP tolerance.
+NLS_KNIFE_EDGE = 1.0e-8
+
+
+def knife_edge_rule(label, oprob, oparams, guesses, term, nit, rterm, rnit, retraction=None, max_fraction=0.1):
+    """The problems whose (termination, iteration count) differ from the oracle's must each sit on a knife edge of the ORACLE's run: the
+    oracle is re-run with decision margins logged.  Returns the mask of agreeing problems; the findings go to
+    gpurun_out/nls_disagreements.jsonl."""
+    import json
+    import os
+    from oracle import margins as M
+    guesses = np.asarray(guesses, dtype=float)
+    same = (np.asarray(term) == np.asarray(rterm)) & (np.asarray(nit) == np.asarray(rnit))
+    rows = []
+    for p in np.flatnonzero(~same):
+        o = N.ConstrainedNonlinearLeastSquares(oprob, retraction=retraction, track_margins=True)
+        o.solve(oparams, guesses[p])
+        qp = min([mm[2] for mm in o.margins if mm[1] == "qp"], default=np.inf)
+        outer = min([(mm[2], mm[0], mm[1]) for mm in o.margins if mm[1] != "qp"], default=(np.inf, -1, ""))
+        rows.append({"test": label, "problem": int(p), "device": [int(term[p]), int(nit[p])], "oracle": [int(rterm[p]), int(rnit[p])],
+                     "min_qp_margin": float(qp), "min_outer_margin": float(outer[0]), "outer_decision": [int(outer[1]), outer[2]]})
+        assert qp < M.KNIFE_EDGE or outer[0] < NLS_KNIFE_EDGE, (
+            f"{label}: problem {p} ends {(term[p], nit[p])} on the device and {(rterm[p], rnit[p])} in the oracle although no decision of the "
+            f"oracle's run was near its threshold (inner QP {qp:.2e}, outer loop {outer[0]:.2e} at {outer[1:]})")
+    if rows:
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "nls_disagreements.jsonl"), "a") as f:
+            for row in rows:
+                f.write(json.dumps(row) + "\n")
+    assert (~same).mean() <= max_fraction, (label, float((~same).mean()))
+    return same
+
+
 def params_pair(**kw):
     return N.Params(**kw), NLS.Params(**kw)
 
@@ -141,8 +178,8 @@ def test_himmelblau_grids(quadrant):
     assert dist.max() < 5e-5
     # problem-by-problem agreement with the oracle's run of the reference algorithm (knife-edge branch decisions may flip
     # with rounding in a few starts; those still have to reach an optimum, checked above)
-    same = (term == rterm) & (nit == rnit)
-    assert same.mean() > 0.97, same.mean()
+    same = knife_edge_rule(f"himmelblau quadrant={quadrant}", N.Problem(2, P.himmelblau_np, inequality_constraints=cons), op, guesses,
+                           term, nit, rterm, rnit, max_fraction=0.03)
     np.testing.assert_allclose(x[same], rx[same], atol=1e-6)
 
 
@@ -158,8 +195,8 @@ def test_sphere_with_nonlinear_equality_constraints():
     dist = np.min(np.linalg.norm(x[:, None, :] - sols[None], axis=2), axis=1)
     assert dist.max() < 5e-5
     assert int(out.NumFailedLineSearches().sum()) == 0
-    same = (term == rterm) & (nit == rnit)
-    assert same.mean() > 0.9, same.mean()
+    # (relative_exit_tol = 1e-12 makes the reference's own exit test a comparison at rounding level once the iteration has converged)
+    same = knife_edge_rule("sphere", N.Problem(6, P.sphere_np, equality=P.sphere_eq_np), op, P.sphere_guesses(100), term, nit, rterm, rnit)
     np.testing.assert_allclose(x[same], rx[same], atol=1e-6)
 
 
@@ -360,8 +397,8 @@ def test_nls_on_the_fused_solve_kernel_with_per_problem_lambda():
         np.testing.assert_allclose(x[sat, 2 * q] * x[sat, 2 * q + 1], prods[q], atol=1e-6)
         np.testing.assert_allclose(np.abs(x[sat, 2 * q]), np.sqrt(prods[q]), atol=5e-4)
     np.testing.assert_allclose(x[sat][:, 2 * k:], 0.0, atol=5e-5)
-    same = (term == rterm) & (nit == rnit)
-    assert same.mean() > 0.9, same.mean()
+    same = knife_edge_rule("sphere with product pairs and boxes", N.Problem(n, cost_np, equality=eq_np, inequality_constraints=cons), op, guesses,
+                           term, nit, rterm, rnit)
     np.testing.assert_allclose(x[same], rx[same], atol=1e-6)
     # lambda really differs from problem to problem along the way (the per-problem vector is exercised)
     lam = out.iterations.cpu().numpy()[:, :, 1]
@@ -493,14 +530,15 @@ def test_two_angle_actuator_chain_on_device(stage):
     assert int(out.NumLineSearchSteps().max()) < 100
     term, nit = out.termination_state.cpu().numpy(), out.num_iterations.cpu().numpy()
     cost, eq = P.chain_rows_np(spec, spec["cost_rows"]), P.chain_rows_np(spec, spec["eq_rows"])
-    same = 0
+    oprob = N.Problem(2, cost, equality=eq, inequality_constraints=cons)
+    rterm, rnit, rx = [], [], []
     for p, g in enumerate(guesses):
-        o = N.ConstrainedNonlinearLeastSquares(N.Problem(2, cost, equality=eq, inequality_constraints=cons), retraction=P.mod_pi_retraction_np)
+        o = N.ConstrainedNonlinearLeastSquares(oprob, retraction=P.mod_pi_retraction_np)
         t, logs = o.solve(N.Params(**prm), g)
-        if t == term[p] and len(logs) == nit[p]:
-            same += 1
-            np.testing.assert_allclose(x[p], o.variables, atol=1e-6)
-    assert same >= 0.97 * len(guesses), (same, len(guesses))   # knife-edge line-search decisions may flip with rounding in a few starts
+        rterm.append(t); rnit.append(len(logs)); rx.append(o.variables.copy())
+    same = knife_edge_rule(f"two-angle chain stage {stage}", oprob, N.Params(**prm), guesses, term, nit, rterm, rnit,
+                           retraction=P.mod_pi_retraction_np, max_fraction=0.03)
+    np.testing.assert_allclose(x[same], np.array(rx)[same], atol=1e-6)
 
 
 def test_two_angle_with_a_callback_retraction_matches_the_builtin():
@@ -634,3 +672,27 @@ def test_problem_of_residuals_matches_the_dense_stack():
     res = NLS.MakeResidual((2, 3), product(9.0), 1)
     assert res.Dimension() == 1
     np.testing.assert_allclose(res.QuadraticError(T(guesses)).cpu().numpy(), 0.5 * (guesses[:, 2] * guesses[:, 3] - 9.0) ** 2, rtol=1e-14)
+
+
+@pytest.mark.parametrize("n,k,m_r", [(150, 6, 170), (186, 4, 192), (144, 8, 150)])
+def test_null_space_solver_fp32_with_more_than_144_variables(n, k, m_r):
+    """fp32 plans reach n = 145 ... 190 (n + k <= 192 and the LDS fits): the J^T J register tiling of the null-space kernel must cover
+    every column there (16 x 12 blocks beyond 144; with 16 x 9 the rows and columns >= 144 of J^T J were never accumulated and the
+    solver returned a wrong x with SUCCESS).  Referee: the oracle's QR / Cholesky restatement in fp64 on the fp32-rounded inputs."""
+    rng = np.random.default_rng(n + k)
+    B = 5
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    J = f(rng.uniform(-1, 1, (B, m_r, n))); r = f(rng.uniform(-1, 1, (B, m_r)))
+    A = f(rng.uniform(-1, 1, (B, k, n))); b = f(rng.uniform(-1, 1, (B, k)))
+    lam = float(np.float32(0.25))
+    dt = torch.float32
+    s = Q.QPNullSpaceSolver()
+    term = s.Solve(Q.BatchedQP(n=n, k=k, J=T(J, dt), r=T(r, dt), lam=lam, A_eq=T(A.transpose(0, 2, 1), dt), b_eq=T(b, dt)))
+    assert torch.all(term == Q.QPNullSpaceSolver.SUCCESS)
+    x = s.variables().double().cpu().numpy()
+    for p in range(B):
+        G = J[p].T @ J[p] + lam * np.eye(n)
+        ok, xr = N.null_space_solve(N.QPData(np.tril(G), J[p].T @ r[p], A[p], b[p], []))
+        assert ok
+        assert np.abs(x[p] - xr).max() <= 2e-3 * max(1.0, np.abs(xr).max()), (p, np.abs(x[p] - xr).max())
+        assert np.abs(A[p] @ x[p] + b[p]).max() <= 1e-3

@@ -55,6 +55,29 @@ def batch_to_device(hb, dt=torch.float64):
                        cons_b=T(hb.cons_b, dt))
 
 
+def solves_agree_or_knife_edge(tag, make_qp, kw, runs, max_fraction=0.12):
+    """`runs` = {label: (termination [B], iterations [B])} of device Solves of the same problems.  Wherever two runs differ, or one differs
+    from the oracle, the oracle is the referee (oracle/margins.py): the problem must sit on a knife edge of the ORACLE's run -- a decision
+    within rounding of its threshold -- or be one the oracle itself cannot converge on (MAX_ITERATIONS: random constraint sets can be
+    infeasible or degenerate, multipliers reach 1e12 and there is no trajectory to follow).  Returns the mask of problems on which every
+    run agrees with every other."""
+    from oracle import margins as M
+    labels = list(runs)
+    B = len(runs[labels[0]][0])
+    agree = np.ones(B, dtype=bool)
+    for a_ in labels[1:]:
+        agree &= (np.asarray(runs[a_][0]) == np.asarray(runs[labels[0]][0])) & (np.asarray(runs[a_][1]) == np.asarray(runs[labels[0]][1]))
+    for p in np.flatnonzero(~agree):
+        term, n_it, _, marg = M.solve_with_margins(make_qp(p), **kw)
+        if term == orc.MAX_ITERATIONS:
+            continue
+        mm, where = M.min_margin(marg)
+        assert mm < M.KNIFE_EDGE, (f"{tag}: problem {p}: " + ", ".join(f"{l} ends ({int(runs[l][0][p])}, {int(runs[l][1][p])})" for l in labels)
+                                    + f", the oracle ({term}, {n_it}) with no decision closer than {mm:.2e} to its threshold ({where})")
+    assert (~agree).mean() <= max_fraction, (tag, float((~agree).mean()))
+    return agree
+
+
 def rel_inf_rows(got, ref):
     return np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
 
@@ -879,8 +902,8 @@ def test_fused_padded_sizes(n, k, m, m_r, level):
         out = sv.Solve(Q.Params(**kw))
         assert torch.all(out.status == 0)
         res[force] = (sv.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
-    same = (res[False][1] == res[True][1]) & (res[False][2] == res[True][2])
-    assert same.mean() >= 0.9
+    make_qp = lambda p: orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+    same = solves_agree_or_knife_edge((n, k, m, m_r, level), make_qp, kw, {"fused": (res[False][2], res[False][1]), "generic": (res[True][2], res[True][1])})
     np.testing.assert_allclose(res[False][0][same], res[True][0][same], rtol=1e-6, atol=1e-8)
 
 
@@ -986,8 +1009,11 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
         np.testing.assert_allclose(f[1], g_[1], atol=1e-8, err_msg=str(tag))
         np.testing.assert_allclose(f[2], g_[2], rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=str(tag))
         np.testing.assert_allclose(f[3], g_[3], rtol=1e-7, atol=1e-9, err_msg=str(tag))
-        same = (f[5] == g_[5]) & (f[6] == g_[6])
-        assert same.mean() >= 0.75, (tag, f[5], g_[5])
+        Gd = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); cd = np.einsum("bqi,bq->bi", J, r)
+        make_qp = lambda p: orc.QP(G=np.tril(Gd[p]), c=cd[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+        solve_kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=kkt_tol, max_iterations=10, barrier_strategy=strategy,
+                        initial_guess_method=orc.GUESS_SOLVE_EQUALITY_CONSTRAINED if k else orc.GUESS_NAIVE)
+        same = solves_agree_or_knife_edge(tag, make_qp, solve_kw, {"fused": (f[6], f[5]), "generic": (g_[6], g_[5])}, max_fraction=0.25)
         # optimum: x of the problems that converged (random constraint sets can be nearly degenerate: multipliers reach 1e12, the
         # interior-point loop runs into MAX_ITERATIONS and the two summation orders drift apart there)
         conv = same & (f[6] == Q.SATISFIED_KKT_TOL)
@@ -999,8 +1025,9 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
             assert "tiny" not in s32.solve_kernel() and s32.solve_kernel().startswith("fused"), s32.solve_kernel()
             o32 = s32.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=kkt_tol, max_iterations=10, barrier_strategy=strategy,
                                      initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
-            same32 = (o32.num_iterations.cpu().numpy() == f[5]) & (o32.termination_state.cpu().numpy() == f[6])
-            assert same32.mean() >= 0.75, (tag, o32.num_iterations, f[5])
+            same32 = solves_agree_or_knife_edge(tag + ("32 grid",), make_qp, solve_kw,
+                                                {"one_tile": (f[6], f[5]), "grid32": (o32.termination_state.cpu().numpy(), o32.num_iterations.cpu().numpy())},
+                                                max_fraction=0.25)
             c32 = same32 & (f[6] == Q.SATISFIED_KKT_TOL)
             if c32.any():
                 x32 = s32.variables().cpu().numpy()[c32][:, :n]
@@ -1368,8 +1395,11 @@ def test_fused_odd_n_with_stacked_jacobian(n, k, m, m_r):
         assert torch.all(out.status == 0)
         res[force] = (after, sv.variables().cpu().numpy().copy(), out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy())
     np.testing.assert_allclose(res[False][0], res[True][0], rtol=1e-8, atol=1e-10)
-    same = (res[False][2] == res[True][2]) & (res[False][3] == res[True][3]) & (res[False][3] == Q.SATISFIED_KKT_TOL)
-    assert same.mean() >= 0.7, (res[False][2], res[True][2], res[False][3])
+    Gd = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); cd = np.einsum("bqi,bq->bi", J, r)
+    make_qp = lambda p: orc.QP(G=np.tril(Gd[p]), c=cd[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+    same = solves_agree_or_knife_edge((n, k, m, m_r), make_qp, kw, {"fused": (res[False][3], res[False][2]), "generic": (res[True][3], res[True][2])},
+                                      max_fraction=0.3)
+    same &= res[False][3] == Q.SATISFIED_KKT_TOL
     np.testing.assert_allclose(res[False][1][same][:, :n], res[True][1][same][:, :n], rtol=1e-6, atol=1e-8)
 
 
@@ -1431,3 +1461,82 @@ def test_fused_kernels_take_every_layout_of_J(n, k, m, m_r):
         for a_, b_ in zip((got[0], got[1][0], got[1][1], got[2], got[3], got[4]), (base[0], base[1][0], base[1][1], base[2], base[3], base[4])):
             np.testing.assert_allclose(a_, b_, rtol=1e-12, atol=1e-13, equal_nan=True, err_msg=label)
         assert np.array_equal(got[5], base[5]) and np.array_equal(got[6], base[6]), label
+
+
+# ------------------------------------------------------------------ Params::decrease_mu_only_on_small_error (qp.hpp:154-157, qp.cc:140-146)
+@pytest.mark.parametrize("shape", [(8, 2, 4, 16), (32, 4, 16, 64), (64, 8, 32, 128), (64, 24, 32, 128), (100, 8, 30, 128)],
+                         ids=["one_tile", "grid32", "grid64", "two_y_tiles", "grid128"])
+@pytest.mark.parametrize("strategy", [Q.COMPLEMENTARITY, Q.FIXED_DECREASE, Q.PREDICTOR_CORRECTOR])
+def test_decrease_mu_only_on_small_error(shape, strategy):
+    """With the flag set mu is only decreased after an iteration whose kkt_after.Max() <= mu.  Started from initial_mu = 1e-3 the first
+    iterations of these problems end ABOVE mu, so the gate holds mu where the ungated Solve decreases it (checked: the records differ from
+    the ungated run on every problem): every kernel family -- one-tile, fused 32 / 64 / 128 grids, two y tiles, generic -- must follow the
+    oracle's gated run iteration for iteration (termination, iteration count, the mu of every iteration record, the optimum)."""
+    from oracle import margins as M
+    n, k, m, m_r = shape
+    B = 12
+    hb = synth.make_batch(n, k, m, m_r, B, stream=33)
+    kw = dict(initial_mu=1e-3, sigma=0.1, termination_kkt_tol=1e-9, max_iterations=30, barrier_strategy=strategy)
+    ref, ungated = [], []
+    for p in range(B):
+        G, c, _ = orc.linearize_dense(hb.J[p], hb.r[p], hb.lam)
+        qp = orc.QP(G=G, c=c, A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=hb.cons_var[p], cons_a=hb.cons_a[p], cons_b=hb.cons_b[p])
+        o = orc.Solver(qp)
+        term, its = o.solve(decrease_mu_only_on_small_error=1, **kw)
+        t2, n2, v2, marg = M.solve_with_margins(qp, decrease_mu_only_on_small_error=1, **kw)
+        assert (t2, n2) == (term, len(its))
+        ref.append((term, [i.ip.mu for i in its], o.variables.copy(), marg))
+        o0 = orc.Solver(qp)
+        _, its0 = o0.solve(decrease_mu_only_on_small_error=0, **kw)
+        ungated.append([i.ip.mu for i in its0])
+    assert all(r[1] != u for r, u in zip(ref, ungated))             # the gate matters on every problem
+    for force in (False, True):
+        if force and n + k > 120:
+            continue                                                # the LDS-resident generic kernel does not hold the 128 grid's shapes
+        s = Q.QPInteriorPointSolver(batch_to_device(hb), force_generic=force)
+        if not force:
+            assert s.solve_kernel().startswith("fused"), s.solve_kernel()
+        out = s.Solve(Q.Params(decrease_mu_only_on_small_error=True, **kw))
+        assert torch.all(out.status == 0)
+        tm, nit = out.termination_state.cpu().numpy(), out.num_iterations.cpu().numpy()
+        rec, v = out.iterations.cpu().numpy(), s.variables().cpu().numpy()
+        dis = M.Disagreements(f"gated Solve {shape} strategy {strategy} {'generic' if force else s.solve_kernel()}")
+        for p in range(B):
+            term, mus, x_ref, marg = ref[p]
+            same = tm[p] == term and nit[p] == len(mus)
+            dis.check(p, same, marg)
+            if same:
+                # PREDICTOR_CORRECTOR records sigma mu of the corrector (qp.cc:183), a cube of a ratio: a little looser
+                np.testing.assert_allclose(rec[p, :len(mus), 8], mus, rtol=1e-6 if strategy == Q.PREDICTOR_CORRECTOR else 1e-9, atol=1e-300)
+                np.testing.assert_allclose(v[p], x_ref, rtol=1e-7, atol=1e-9)
+        assert len(dis.items) <= 1, dis.report()
+
+
+@pytest.mark.parametrize("n,k,m,m_r", [(64, 8, 32, 128), (128, 16, 64, 256)])
+def test_decrease_mu_only_on_small_error_fp32(n, k, m, m_r):
+    """The fp32 Solve kernel with the gate: fp32 has no reference counterpart, so the referee is the fp64 fused kernel (pinned to the oracle
+    above) on the same fp32-rounded inputs.  The gate must hold mu in fp32 wherever it does in fp64 while the KKT error is well above mu
+    (the first iterations; later ones sit within fp32 rounding of the threshold), and the run must reach the same optimum."""
+    B = 12
+    hb = synth.make_batch(n, k, m, m_r, B, stream=34)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    kw = dict(initial_mu=1e-3, sigma=0.1, termination_kkt_tol=2e-3, termination_complementarity_tol=1e-3, max_iterations=30,
+              barrier_strategy=Q.FIXED_DECREASE)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=T(f(hb.J), dt), r=T(f(hb.r), dt), lam=float(np.float32(hb.lam)), A_eq=T(f(hb.A_eq), dt),
+                           b_eq=T(f(hb.b_eq), dt), cons_var=T(hb.cons_var, torch.int32), cons_a=T(f(hb.cons_a), dt), cons_b=T(f(hb.cons_b), dt))
+        for gate in (False, True):
+            s = Q.QPInteriorPointSolver(prob)
+            assert s.solve_kernel().startswith("fused_solve"), s.solve_kernel()
+            out = s.Solve(Q.Params(decrease_mu_only_on_small_error=gate, **kw))
+            assert torch.all(out.status == 0)
+            res[dt, gate] = (out.termination_state.cpu().numpy(), out.num_iterations.cpu().numpy(), out.iterations.double().cpu().numpy(),
+                             s.variables().double().cpu().numpy())
+    t32, n32, r32, v32 = res[torch.float32, True]
+    t64, n64, r64, v64 = res[torch.float64, True]
+    assert np.all(t32 == Q.SATISFIED_KKT_TOL) and np.all(t64 == Q.SATISFIED_KKT_TOL)
+    assert not np.array_equal(res[torch.float32, False][2][:, :3, 8], r32[:, :3, 8])          # the gate changes the fp32 run ...
+    np.testing.assert_allclose(r32[:, :3, 8], r64[:, :3, 8], rtol=1e-5)                        # ... exactly as it changes the fp64 one
+    assert np.abs(n32 - n64).max() <= 2
+    assert np.abs(v32[:, :n] - v64[:, :n]).max() <= 5e-3 * max(1.0, np.abs(v64[:, :n]).max())

@@ -125,3 +125,74 @@ def test_solve_on_ill_conditioned_hessians():
             v, nit, tm = res[force]
             assert tm[p] == term and nit[p] == len(its), (p, force, tm[p], term, nit[p], len(its))
             assert np.abs(v[p][:hb.n] - o.variables[:hb.n]).max() <= 1e-6 * max(1.0, np.abs(o.variables[:hb.n]).max())
+
+
+def overconstrained_problem(rng, n, k, m, B):
+    """The construction of tests/test_gpu_fuzz.py (a QP around a strictly feasible point x0) with k close to n and / or m >> n, and the
+    state Solve starts from: ComputeInitialGuess NAIVE (qp.cc:439-482) clamps x = 0 into the constraints one after the other; with several
+    constraints per variable the clamps undo each other, slacks end at the floor 1e-9 and z = 1 / s = 1e9, i.e. z / s = 1e18."""
+    import ctypes as C
+    m_r = n + 8
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m))
+    x0 = rng.uniform(-0.5, 0.5, (B, n)); b = -np.einsum("bik,bi->bk", A, x0)
+    cb = -ca * np.take_along_axis(x0, cv.astype(np.int64), axis=1) + rng.uniform(0.05, 0.5, (B, m))
+    lam = 1e-2
+    hb = type("Batch", (), {})()
+    hb.n, hb.k, hb.m, hb.batch, hb.lam = n, k, m, B, lam
+    hb.J, hb.r, hb.A_eq, hb.b_eq, hb.cons_var, hb.cons_a, hb.cons_b = J, r, A, b, cv, ca, cb
+    hb.vars = np.zeros((B, n + 2 * m + k)); hb.mu = np.ones(B)
+    for p in range(B):
+        Gl, cl, _ = orc.linearize_dense(J[p], r[p], lam)
+        o = orc.Solver(orc.QP(G=Gl, c=cl, A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p]))
+        prm = orc._Params()
+        o.L.orc_default_params(C.byref(prm))
+        prm.initial_guess_method = orc.GUESS_NAIVE
+        assert o.L.orc_initial_guess(C.byref(o._s), C.byref(prm)) == 0
+        hb.vars[p] = o.variables
+    return hb
+
+
+@pytest.mark.parametrize("n,k,m", [(20, 18, 64), (32, 30, 64), (12, 2, 64), (116, 7, 12), (64, 31, 64), (40, 38, 10)])
+def test_first_step_from_an_overconstrained_naive_start(n, k, m):
+    """Over-constrained random problems (k close to n, or m >> n): from the NAIVE start with slacks on the 1e-9 floor (z / s = 1e18) the
+    oracle, the fused and the generic kernel follow different Solve trajectories (seen in a soak of tests/test_gpu_fuzz.py, which is why
+    that test draws well-posed shapes).  Here the FIRST step of each is measured against the long-double truth: the barrier diagonal
+    a^2 z / s = 1e18 sits beside G = O(n) and A_eq = O(1), so the reduced KKT matrix has cond ~ 1e18 / lambda_min and every double-precision
+    formulation loses digits in the variables that carry no floor slack.  The bar: the device kernels are not worse than the reference
+    arithmetic (the oracle's explicit-inverse path) by more than a small factor.  The measured errors go to
+    gpurun_out/stress_overconstrained.jsonl (DESIGN.md section 2 quotes them)."""
+    import json, os
+    rng = np.random.default_rng(1000 * n + 10 * k + m)
+    hb = overconstrained_problem(rng, n, k, m, 4)
+    floor = (hb.vars[:, n:n + m] <= 1.0e-9).sum(axis=1)
+    assert floor.max() > 0                                    # the case is what it claims to be
+    dev = {}
+    for label, force in (("fused", False), ("generic", True)):
+        try:
+            s = Q.QPInteriorPointSolver(device_problem(hb), force_generic=force)
+            s.SetVariables(T(hb.vars))
+            _, status = s.Iterate(T(hb.mu), Q.COMPLEMENTARITY)
+        except Exception as e:                                # the LDS-resident generic kernel does not hold every shape
+            assert force and "LDS" in str(e), e
+            continue
+        assert torch.all(status == 0), label
+        dev[label + "_iterate"] = s.delta_.cpu().numpy().copy()
+    rows = []
+    for p in range(hb.batch):
+        tr, oerr, cond, ratio = per_problem(hb, p)
+        row = {"n": n, "k": k, "m": m, "p": p, "slacks_on_floor": int(floor[p]), "cond_reduced_kkt": float(cond), "oracle_inverse": float(oerr["inverse"]),
+               "oracle_direct": float(oerr["direct"])}
+        for label, d in dev.items():
+            row[label] = float(np.abs(d[p] - tr).max() / np.abs(tr).max())
+        rows.append(row)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "stress_overconstrained.jsonl"), "a") as f:
+        for row in rows:
+            f.write(json.dumps(row) + "\n")
+    for row in rows:
+        ref_err = max(row["oracle_inverse"], row["oracle_direct"])
+        for label in dev:
+            assert row[label] <= 8 * ref_err + 1e-12, row

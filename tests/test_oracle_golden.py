@@ -239,3 +239,60 @@ def test_predictor_corrector_and_fixed_decrease_converge():
         term, its = s.solve(termination_kkt_tol=1e-10, initial_mu=0.1, sigma=0.1, max_iterations=60, barrier_strategy=strat)
         assert term == orc.SATISFIED_KKT_TOL, strat
         np.testing.assert_allclose(s.variables[:3], [0.5, -1.0, 2.0], atol=1e-6)
+
+
+def _random_qp(rng, n, k, m):
+    """A well-posed QP around a strictly feasible point (the construction of tests/test_gpu_fuzz.py)."""
+    m_r = n + 4
+    J = rng.uniform(-1, 1, (m_r, n)); r = rng.uniform(-1, 1, m_r)
+    A = rng.uniform(-1, 1, (k, n))
+    cv = rng.integers(0, n, m).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], m)
+    x0 = rng.uniform(-0.5, 0.5, n)
+    cb = -ca * x0[cv] + rng.uniform(0.05, 0.5, m)
+    G = np.tril(J.T @ J + 1e-2 * np.eye(n))
+    return orc.QP(G=G, c=J.T @ r, A_eq=A if k else None, b_eq=-(A @ x0) if k else None, cons_var=cv, cons_a=ca, cons_b=cb)
+
+
+@pytest.mark.parametrize("strategy", [orc.COMPLEMENTARITY, orc.FIXED_DECREASE, orc.PREDICTOR_CORRECTOR])
+@pytest.mark.parametrize("gate", [0, 1])
+def test_margin_replay_is_the_oracles_solve(strategy, gate):
+    """oracle/margins.py replays orc_solve through the oracle's primitives to log decision margins: it must BE the oracle's Solve
+    (termination, iteration count, final state bit for bit) for every strategy, guess and with decrease_mu_only_on_small_error."""
+    from oracle import margins as M
+    rng = np.random.default_rng(100 + 10 * strategy + gate)
+    for trial in range(12):
+        n = int(rng.integers(3, 20)); k = int(rng.integers(0, n // 2 + 1)); m = int(rng.integers(1, 2 * n))
+        qp = _random_qp(rng, n, k, m)
+        guess = orc.GUESS_SOLVE_EQUALITY_CONSTRAINED if (k and trial % 2) else orc.GUESS_NAIVE
+        kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=15, barrier_strategy=strategy,
+                  initial_guess_method=guess, decrease_mu_only_on_small_error=gate, initialize_mu_with_complementarity=trial % 3 == 0)
+        o = orc.Solver(qp)
+        term, its = o.solve(**kw)
+        t2, n2, v2, marg = M.solve_with_margins(qp, **kw)
+        assert (t2, n2) == (term, len(its))
+        assert np.array_equal(v2, o.variables)
+        assert marg and all(np.isfinite(mm[2]) or mm[1] == "mu_gate" for mm in marg)
+        assert any(mm[1] == "mu_gate" for mm in marg) == bool(gate)
+
+
+def test_decrease_mu_only_on_small_error_changes_the_trajectory():
+    """qp.cc:140-146 / qp.hpp:154-157: with the flag set mu is only decreased once kkt_after.Max() <= mu.  On these problems the first
+    iterations end with kkt_after.Max() > mu, so the gated run keeps its mu where the ungated one decreases it: different iteration
+    records, same optimum.  (The device tests use the same problems, tests/test_gpu_parity.py::test_decrease_mu_only_on_small_error.)"""
+    rng = np.random.default_rng(5)
+    held = 0
+    for trial in range(8):
+        qp = _random_qp(rng, 12, 3, 10)
+        kw = dict(initial_mu=1e-3, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=40, barrier_strategy=orc.FIXED_DECREASE)
+        a, b = orc.Solver(qp), orc.Solver(qp)
+        ta, ia = a.solve(decrease_mu_only_on_small_error=0, **kw)
+        tb, ib = b.solve(decrease_mu_only_on_small_error=1, **kw)
+        assert ta == tb == orc.SATISFIED_KKT_TOL
+        np.testing.assert_allclose(a.variables[:12], b.variables[:12], atol=2e-5)   # both within the complementarity tolerance 1e-6 of the optimum
+        # the gate held mu at least once: some iteration of the gated run starts with the mu of the one before
+        mus = [it.ip.mu for it in ib]
+        held += int(any(mus[i + 1] == mus[i] for i in range(len(mus) - 1)))
+        kmax0 = max(ib[0].kkt_final.r_dual, ib[0].kkt_final.r_comp, ib[0].kkt_final.r_primal_eq, ib[0].kkt_final.r_primal_ineq)
+        if mus[1] == mus[0]:
+            assert kmax0 > mus[0]
+    assert held >= 6, held

@@ -68,3 +68,14 @@ def test_two_rank_sharded_step_matches_single_rank(tmp_path):
     np.testing.assert_array_equal(got, ref)  # sharding changes nothing: problems are independent
     agg = np.load(tmp_path / "agg.npy")
     assert agg[0] == 1.5 and agg[1] == total  # MAX of the per-rank times, SUM of the per-rank unit counts
+
+
+def test_synthetic_generator_rejects_shapes_it_cannot_build():
+    """synth.make_batch_torch puts a lower and an upper bound on each of m / 2 DISTINCT variables: m must be even and <= 2 n.  The check
+    runs on the host before any device op (an out-of-range gather on the device once faulted a GPU box); on a machine without a GPU it is
+    reached before the first tensor is created."""
+    import pytest
+    from mini_opt_amd import synth
+    for n, m in ((8, 18), (4, 10), (8, 5), (3, 7)):
+        with pytest.raises(ValueError, match="even m <= 2 n"):
+            synth.make_batch_torch(n, 2, m, 16, 4, "cpu", None, seed=1)
