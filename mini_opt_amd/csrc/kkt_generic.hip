@@ -113,6 +113,45 @@ __host__ __device__ inline size_t ws_elems(int n, int k, int m, int m_r) {
   return e;
 }
 
+// ---- LARGE systems (P = n + k beyond the register-distributed factorisation's 192, or an H that does not fit the LDS): H lives in a global
+// workspace of the workgroup (P x ldh, column-major, plan-owned, L2-resident: one per workgroup of the persistent grid), everything else stays
+// in LDS.  The J row chunk and the factorisation's column panel share one LDS region (they are never live together).
+__host__ __device__ inline int large_ld(int P) { return (P + 1) & ~1; }
+__host__ __device__ inline int panel_cols_for(int n, int k, int m, int m_r, int elem) {
+  // widest panel (32 / 16 / 8 columns of P | 1 rows) that fits beside the vectors
+  const int P = n + k, V = n + 2 * m + k;
+  const size_t vec = (4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + 16) * elem + (size_t)(m + 8) * sizeof(int) + 64;
+  for (int nb = 32; nb >= 8; nb >>= 1)
+    if (vec + (size_t)(P | 1) * nb * elem <= 160 * 1024) return nb;
+  return 0;
+}
+template <typename T>
+__host__ __device__ inline size_t ws_elems_large(int n, int k, int m, int m_r) {
+  const int P = n + k, V = n + 2 * m + k;
+  const int cr = chunk_rows_for(n, m_r, (int)sizeof(T));
+  const int nb = panel_cols_for(n, k, m, m_r, (int)sizeof(T));
+  const size_t chunk = (size_t)cr * n + cr, panel = (size_t)(P | 1) * nb;
+  return 4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + (chunk > panel ? chunk : panel) + 16;
+}
+template <typename T>
+__device__ inline void carve_large(Ws<T>& w, char* smem, T* H_global, int n, int k, int m, int m_r) {
+  const int P = n + k, V = n + 2 * m + k;
+  T* p = reinterpret_cast<T*>(smem);
+  w.ldh = large_ld(P);
+  w.H = H_global;
+  w.vars = p; p += V; w.res = p; p += V; w.delta = p; p += V; w.daff = p; p += V;
+  w.cvec = p; p += n; w.beq = p; p += k;
+  w.rhs = p; p += P; w.invd = p; p += P;
+  w.ca = p; p += m; w.cb = p; p += m;
+  w.chunk_rows = chunk_rows_for(n, m_r, (int)sizeof(T));
+  const int nb = panel_cols_for(n, k, m, m_r, (int)sizeof(T));
+  const size_t chunk = (size_t)w.chunk_rows * n + w.chunk_rows, panel = (size_t)(P | 1) * nb;
+  w.Jc = p; w.rc = p + (size_t)w.chunk_rows * n; p += (chunk > panel ? chunk : panel);   // (the panel overlays the J chunk)
+  w.red = p; p += 16;
+  w.cv = reinterpret_cast<int*>(p);
+  w.iflag = w.cv + m;
+}
+
 template <typename T>
 __device__ inline void carve(Ws<T>& w, char* smem, int n, int k, int m, int m_r) {
   const int P = n + k, V = n + 2 * m + k;
@@ -146,6 +185,9 @@ __device__ inline double sqrtT(double v) { return sqrt(v); }
 __device__ inline float sqrtT(float v) { return sqrtf(v); }
 template <typename T> __device__ inline T nanT() { return (T)__builtin_nan(""); }
 template <typename T> __device__ inline bool finiteT(T v) { return __builtin_isfinite(v); }
+
+// Orders one wave's own LDS traffic: values another lane of the SAME wave stored are visible to the loads that follow.
+__device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
@@ -208,9 +250,42 @@ __device__ inline void jtj_tile_rows_impl(const Ws<T>& w, int n, int rows, int t
       if (i < n && j <= i) w.H[i + (size_t)j * w.ldh] += acc[bi * (bi + 1) / 2 + bj];
     }
 }
+// LARGE: the same register tiling over 96 x 96 super-blocks of G (16 x 16 threads x 6 x 6 blocks), lower block triangle only; G is in global memory.
+template <typename T, bool DIAG>
+__device__ inline void jtj_superblock(const Ws<T>& w, int n, int rows, int I0, int J0, int tid) {
+  constexpr int TG = 16, RN = 6;
+  const int ti = tid & (TG - 1), tj = tid / TG;
+  T acc[RN * RN];
+#pragma unroll
+  for (int e = 0; e < RN * RN; ++e) acc[e] = (T)0;
+  int ic[RN], jc[RN];
+#pragma unroll
+  for (int b = 0; b < RN; ++b) {
+    ic[b] = I0 + ti + TG * b < n ? I0 + ti + TG * b : n - 1;
+    jc[b] = J0 + tj + TG * b < n ? J0 + tj + TG * b : n - 1;
+  }
+  for (int q = 0; q < rows; ++q) {
+    const T* row = w.Jc + (size_t)q * n;
+    T a[RN], b[RN];
+#pragma unroll
+    for (int e = 0; e < RN; ++e) { a[e] = row[ic[e]]; b[e] = row[jc[e]]; }
+#pragma unroll
+    for (int bi = 0; bi < RN; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < RN; ++bj)
+        if (!DIAG || bj <= bi) acc[bi * RN + bj] += a[bi] * b[bj];
+  }
+#pragma unroll
+  for (int bi = 0; bi < RN; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < RN; ++bj) {
+      const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
+      if ((!DIAG || bj <= bi) && i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] += acc[bi * RN + bj];
+    }
+}
 // H.lower(n x n) += J^T J, cvec = J^T r, diag += lambda; returns 0.5|r|^2 in w.red[8]   (residual.hpp:206-225,
 // nonlinear.cc:182-189).  H must be zero in its n x n block and cvec is overwritten.
-template <typename T, int TG, int R>
+template <typename T, int TG, int R, bool LARGE = false>
 __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r,
                                T lambda, int tid) {
   for (int i = tid; i < n; i += kThreads) w.cvec[i] = (T)0;
@@ -234,7 +309,14 @@ __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T
     __syncthreads();
     // 2-D register tiling: thread (ti, tj) of a TG x TG grid accumulates G(i, j) for i = ti + TG bi, j = tj + TG bj, bi >= bj: per row of
     // J it reads RN + RN operands (broadcasts) for RN (RN + 1) / 2 FMAs, instead of five LDS reads for four FMAs
-    jtj_tile_rows_impl<T, TG, R>(w, n, rows, tid);   // n <= n + k <= TG R
+    if constexpr (LARGE) {
+      for (int I0 = 0; I0 < n; I0 += 96) {
+        for (int J0 = 0; J0 < I0; J0 += 96) jtj_superblock<T, false>(w, n, rows, I0, J0, tid);
+        jtj_superblock<T, true>(w, n, rows, I0, I0, tid);
+      }
+    } else {
+      jtj_tile_rows_impl<T, TG, R>(w, n, rows, tid);   // n <= n + k <= TG R
+    }
     for (int i = tid; i < n; i += kThreads) {
       T acc = 0;
       for (int q = 0; q < rows; ++q) acc += w.Jc[(size_t)q * n + i] * w.rc[q];
@@ -408,9 +490,117 @@ __device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
   return MO_STATUS_OK;
 }
 
+// LARGE: right-looking blocked LDL^T with H in global memory (same natural order, same zero-pivot rules, same result layout: W = L D below
+// the diagonal, invd = 1 / D).  Per block column: the panel (all rows below the diagonal block, NB columns) is staged in LDS and factorised
+// there pivot by pivot (one barrier per pivot); the trailing matrix gets its rank-NB update H22 -= W21 D^-1 W21^T straight in global memory
+// (L2-resident), thread (ti, tj) of the 16 x 16 grid owning a 4 x 4 register block of every 64 x 64 tile of the lower triangle.
+template <typename T>
+__device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) {
+  T* const panel = w.Jc;                    // the J chunk is dead by now
+  bool found_zero = false;
+  int status = MO_STATUS_OK;
+  for (int kb = 0; kb < P && status == MO_STATUS_OK; kb += NB) {
+    const int wd = P - kb < NB ? P - kb : NB, rows = P - kb, ldp = rows | 1;
+    for (int idx = tid; idx < rows * wd; idx += kThreads) {
+      const int jj = idx / rows, i = idx - jj * rows;
+      panel[i + (size_t)jj * ldp] = i >= jj ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
+    }
+    __syncthreads();
+    for (int j = 0; j < wd; ++j) {
+      const T d = panel[j + (size_t)j * ldp];                                   // uniform
+      if (!(absT(d) > (T)0)) {                                                  // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
+        bool nz = false;
+        for (int i = j + 1 + tid; i < rows; i += kThreads) nz |= !(panel[i + (size_t)j * ldp] == (T)0);
+        if (nz || !(d == (T)0)) w.iflag[1] = 1;
+        __syncthreads();
+        if (tid == 0) w.invd[kb + j] = (T)0;
+        if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }
+        found_zero = true;
+        continue;
+      }
+      if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; break; }      // non-zero pivot after a zero pivot
+      const T inv = (T)1 / d;
+      if (tid == 0) w.invd[kb + j] = inv;
+      const int rem = wd - j - 1;
+      for (int idx = tid; idx < rem * rows; idx += kThreads) {                  // the panel's remaining columns
+        const int c = idx / rows, i = idx - c * rows, jj = j + 1 + c;
+        if (i >= jj) panel[i + (size_t)jj * ldp] -= panel[i + (size_t)j * ldp] * (panel[jj + (size_t)j * ldp] * inv);
+      }
+      __syncthreads();
+    }
+    if (status != MO_STATUS_OK) break;                                           // uniform
+    for (int idx = tid; idx < rows * wd; idx += kThreads) {                      // W back to H
+      const int jj = idx / rows, i = idx - jj * rows;
+      if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = panel[i + (size_t)jj * ldp];
+    }
+    const int tr = rows - wd;                                                    // trailing rows / columns
+    if (tr > 0) {
+      const int ti = tid & 15, tj = (tid >> 4) & 15;
+      if (tid < 256) {
+        for (int I0 = 0; I0 < tr; I0 += 64) {
+          for (int J0 = 0; J0 <= I0; J0 += 64) {
+            T acc[4][4];
+            int ii[4], jj[4];
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_) {
+              ii[a_] = wd + (I0 + ti + 16 * a_ < tr ? I0 + ti + 16 * a_ : tr - 1);
+              jj[a_] = wd + (J0 + tj + 16 * a_ < tr ? J0 + tj + 16 * a_ : tr - 1);
+#pragma unroll
+              for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = (T)0;
+            }
+            for (int q = 0; q < wd; ++q) {
+              const T inv = w.invd[kb + q];
+              T av[4], bv[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { av[e] = panel[ii[e] + (size_t)q * ldp]; bv[e] = panel[jj[e] + (size_t)q * ldp] * inv; }
+#pragma unroll
+              for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] += av[a_] * bv[b_];
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+              for (int b_ = 0; b_ < 4; ++b_) {
+                const int i = I0 + ti + 16 * a_, j = J0 + tj + 16 * b_;
+                if (i < tr && j <= i) w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] -= acc[a_][b_];
+              }
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();   // the next panel is read by other threads than the ones that wrote it
+  }
+  __syncthreads();
+  return status;
+}
+// LARGE: (L D L^T) sol = rhs in place with H in global memory.  Forward substitution column by column over the whole workgroup (coalesced
+// column reads, one barrier per column); backward substitution as row dot products on wave 0 (column k below the diagonal is contiguous).
+template <typename T>
+__device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int tid) {
+  for (int kk = 0; kk < P; ++kk) {
+    const T tk = w.rhs[kk] * w.invd[kk];
+    const T* col = w.H + (size_t)kk * w.ldh;
+    for (int i = kk + 1 + tid; i < P; i += kThreads) w.rhs[i] -= col[i] * tk;
+    __syncthreads();
+  }
+  if (tid < 64) {
+    for (int kk = P - 1; kk >= 0; --kk) {
+      const T* col = w.H + (size_t)kk * w.ldh;
+      T sacc = (T)0;
+      for (int i = kk + 1 + tid; i < P; i += 64) sacc += col[i] * w.rhs[i];
+      sacc = wave_sum(sacc);
+      if (tid == 0) w.rhs[kk] = (w.rhs[kk] - sacc) * w.invd[kk];
+      wave_lds_fence();
+    }
+  }
+  __syncthreads();
+}
+
 // Reduced-KKT assembly (Sigma on the diagonal, qp.cc:293-298) + LDL^T.  Returns MO_STATUS_*.
-template <typename T, int TG, int R>
-__device__ MO_INLINE_FACTOR int assemble_and_factor(MO_FACTOR_WS(T) w, int n, int k, int m, bool include_ineq, int tid) {
+template <typename T, int TG, int R, bool LARGE = false>
+__device__ MO_INLINE_FACTOR int assemble_and_factor(MO_FACTOR_WS(T) w, int n, int k, int m, bool include_ineq, int tid, int m_r = 0) {
   const int P = n + k;
   if (include_ineq) {
     const T* s = w.vars + n; const T* z = w.vars + n + m + k;
@@ -427,7 +617,8 @@ __device__ MO_INLINE_FACTOR int assemble_and_factor(MO_FACTOR_WS(T) w, int n, in
     __syncthreads();
   }
   // ---- LDL^T with the matrix distributed over the workgroup's REGISTERS (the kernel is instantiated per thread grid TG and block count R)
-  return factor_in_registers<T, TG, R>(w, P, tid);
+  if constexpr (LARGE) return factor_blocked<T>(w, P, panel_cols_for(n, k, m, m_r, (int)sizeof(T)), tid);
+  else return factor_in_registers<T, TG, R>(w, P, tid);
 }
 
 // Solve (L D L^T) sol = rhs in place, wave 0 only; H holds W = L D below the diagonal, invd = 1/D.
@@ -457,7 +648,7 @@ __device__ MO_INLINE void wave_solve(const Ws<T>& w, int P, int lane) {
 }
 
 // SolveForUpdate (qp.cc:318-364) / SolveForUpdateNoInequalities (qp.cc:366-386) with the factorisation in H.
-template <typename T>
+template <typename T, bool LARGE = false>
 __device__ MO_INLINE void solve_for_update(const Ws<T>& w, int n, int k, int m, T mu, bool include_ineq, int tid) {
   const int P = n + k;
   const T* s = w.vars + n; const T* z = w.vars + n + m + k;
@@ -477,8 +668,12 @@ __device__ MO_INLINE void solve_for_update(const Ws<T>& w, int n, int k, int m, 
   }
   for (int q = tid; q < k; q += kThreads) w.rhs[n + q] = -r_pe[q];
   __syncthreads();
-  if (tid < 64) wave_solve(w, P, tid);
-  __syncthreads();
+  if constexpr (LARGE) {
+    block_solve(w, P, tid);
+  } else {
+    if (tid < 64) wave_solve(w, P, tid);
+    __syncthreads();
+  }
   T* dx = w.delta; T* ds = w.delta + n; T* dy = w.delta + n + m; T* dz = w.delta + n + m + k;
   for (int i = tid; i < n; i += kThreads) dx[i] = w.rhs[i];
   for (int q = tid; q < k; q += kThreads) dy[q] = -w.rhs[n + q];                   // py is negated, :353
@@ -534,15 +729,15 @@ __device__ MO_INLINE void compute_mu_affine(const Ws<T>& w, int n, int k, int m,
 
 // Iterate's solve part (qp.cc:163-193), state update excluded.  Residual must be current, H = G + A.
 // ip[6] receives IPIterationOutputs.  Returns MO_STATUS_*.
-template <typename T, int TG, int R>
-__device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input, int strategy, T tau, T* ip, int tid) {
+template <typename T, int TG, int R, bool LARGE = false>
+__device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T mu_input, int strategy, T tau, T* ip, int tid, int m_r = 0) {
   const int V = n + 2 * m + k;
   ip[0] = mu_input; ip[1] = 1; ip[2] = 1; ip[3] = nanT<T>(); ip[4] = nanT<T>(); ip[5] = nanT<T>();
   for (int i = tid; i < V; i += kThreads) w.daff[i] = (T)0;                        // delta_affine_.setZero(), :315
 #ifdef MO_GENERIC_STAMPS
   unsigned long long nd_prev = __builtin_amdgcn_s_memtime();
 #endif
-  const int st = assemble_and_factor<T, TG, R>(w, n, k, m, true, tid);
+  const int st = assemble_and_factor<T, TG, R, LARGE>(w, n, k, m, true, tid, m_r);
 #ifdef MO_GENERIC_PROBE_FENCE
   __threadfence_block();
   __builtin_amdgcn_s_waitcnt(0);
@@ -551,12 +746,12 @@ __device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T
   MO_NDSTAMP(0);
   if (st != MO_STATUS_OK) return st;
   if (m == 0) {
-    solve_for_update(w, n, k, m, (T)0, true, tid);                                // :165-167
+    solve_for_update<T, LARGE>(w, n, k, m, (T)0, true, tid);                                // :165-167
   } else if (strategy != MO_PREDICTOR_CORRECTOR) {
-    solve_for_update(w, n, k, m, mu_input, true, tid);                            // :169
+    solve_for_update<T, LARGE>(w, n, k, m, mu_input, true, tid);                            // :169
     MO_NDSTAMP(1);
   } else {
-    solve_for_update(w, n, k, m, (T)0, true, tid);                                // :173
+    solve_for_update<T, LARGE>(w, n, k, m, (T)0, true, tid);                                // :173
     compute_alpha(w, n, k, m, (T)1, tid);                                         // :174
     ip[3] = w.red[5]; ip[4] = w.red[6];
     for (int i = tid; i < V; i += kThreads) w.daff[i] = w.delta[i];               // :177
@@ -566,7 +761,7 @@ __device__ MO_INLINE int newton_direction(const Ws<T>& w, int n, int k, int m, T
     const T ratio = ip[5] / mu_input;
     const T sigma = ratio * ratio * ratio;                                        // :182
     ip[0] = sigma * mu_input;                                                     // :183
-    solve_for_update(w, n, k, m, ip[0], true, tid);                               // :187
+    solve_for_update<T, LARGE>(w, n, k, m, ip[0], true, tid);                               // :187
   }
   if (m > 0) {                                                                    // :191-193
     compute_alpha(w, n, k, m, tau, tid);
@@ -592,13 +787,15 @@ __device__ MO_INLINE void update_state(const Ws<T>& w, int n, int k, int m, T ap
 // ---- the kernel ------------------------------------------------------------------------------------------------
 // TG x TG = the thread grid of the register-distributed factorisation (8 x 8: single-wave workgroups, 16 x 16: 256 threads),
 // R = ceil((n + k) / TG) blocks per thread and dimension (also the block count of the J^T J register tiling: n <= TG R).
-template <typename T, int MODE, int TG, int R>
+// LARGE: H in the workgroup's global workspace (a.H_work), blocked factorisation, 96-wide J^T J super-blocks: any n + k the LDS vectors allow.
+template <typename T, int MODE, int TG, int R, bool LARGE = false>
 __global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ws<T> w;
   const int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
   const int V = n + 2 * m + k;
-  carve(w, smem, n, k, m, m_r);
+  if constexpr (LARGE) carve_large(w, smem, (T*)a.H_work + (size_t)blockIdx.x * (size_t)a.H_work_stride, n, k, m, m_r);
+  else carve(w, smem, n, k, m, m_r);
   const int tid = threadIdx.x;
   const bool j_level = a.J != nullptr;
 
@@ -642,7 +839,7 @@ __global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a
     MO_GSTAMP(1);
     if (j_level) {
       const T lam = a.lambda_vec ? ((const T*)a.lambda_vec)[p * a.lambda_vec_stride] : (T)a.lambda;  // per-problem LM state
-      accumulate_jtj<T, TG, R>(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, lam, tid);
+      accumulate_jtj<T, TG, R, LARGE>(w, n, m_r, Jp, a.J_ld, a.J_row_major, rp, lam, tid);
       MO_GSTAMP(2);
       if (MODE == MODE_LINEARIZE || MODE == MODE_SOLVE) {
         // LINEARIZE output, or the per-problem G scratch the Solve loop reloads after each factorisation
@@ -680,12 +877,12 @@ __global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a
         eval_kkt(w, n, k, m, !no_ineq, tid);
         MO_GSTAMP(3);
         if (no_ineq) {
-          st = assemble_and_factor<T, TG, R>(w, n, k, m, false, tid);
-          if (st == MO_STATUS_OK) solve_for_update(w, n, k, m, (T)0, false, tid);
+          st = assemble_and_factor<T, TG, R, LARGE>(w, n, k, m, false, tid, m_r);
+          if (st == MO_STATUS_OK) solve_for_update<T, LARGE>(w, n, k, m, (T)0, false, tid);
           ip[0] = mu_p; ip[1] = 1; ip[2] = 1; ip[3] = ip[4] = ip[5] = nanT<T>();
         } else {
           const int strat = (MODE == MODE_ITERATE) ? a.barrier_strategy : MO_COMPLEMENTARITY;
-          st = newton_direction<T, TG, R>(w, n, k, m, mu_p, strat, (T)a.tau, ip, tid);
+          st = newton_direction<T, TG, R, LARGE>(w, n, k, m, mu_p, strat, (T)a.tau, ip, tid, m_r);
         }
       }
       MO_GSTAMP(4);
@@ -734,9 +931,9 @@ __global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a
         __syncthreads();
         if (sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED) {     // :455-460
           eval_kkt(w, n, k, m, false, tid);
-          st = assemble_and_factor<T, TG, R>(w, n, k, m, false, tid);
+          st = assemble_and_factor<T, TG, R, LARGE>(w, n, k, m, false, tid, m_r);
           if (st == MO_STATUS_OK) {
-            solve_for_update(w, n, k, m, (T)0, false, tid);
+            solve_for_update<T, LARGE>(w, n, k, m, (T)0, false, tid);
             for (int i = tid; i < n; i += kThreads) x[i] = w.delta[i];
             for (int q = tid; q < k; q += kThreads) y[q] = w.delta[n + m + q];
           }
@@ -774,7 +971,7 @@ __global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a
         rec[0] = w.red[0]; rec[1] = w.red[1]; rec[2] = w.red[2]; rec[3] = w.red[3];
         __syncthreads();
         // Iterate, qp.cc:153-201 (its leading EvaluateKKTConditions would recompute the residual we already hold)
-        st = newton_direction<T, TG, R>(w, n, k, m, mu, sp.barrier_strategy, (T)0.995, rec + 8, tid);
+        st = newton_direction<T, TG, R, LARGE>(w, n, k, m, mu, sp.barrier_strategy, (T)0.995, rec + 8, tid, m_r);
         if (st != MO_STATUS_OK) break;
         update_state(w, n, k, m, rec[9], rec[10], tid);
         load_qp(w, n, k, Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
@@ -839,8 +1036,6 @@ __global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a
 //   x = u + Q2 y                   (:725)      the reflectors applied to [0; y]
 // A rank-deficient A_eq (rank r < k): Q1 = first r columns, R1 = leading r x r block (the reference's own k x k solve against Q1's r
 // columns is a size mismatch there -- an Eigen assertion --, so this follows the consistent reading: solve with R1 only).
-// Orders one wave's own LDS traffic: values another lane of the SAME wave stored are visible to the loads that follow.
-__device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // LDS layout of the null-space kernel: G (n x n, odd leading dimension) | M = A_eq^T (n x k, same leading dimension) | u, g, pv, wv,
 // cvec (n each) | beq, tau, pidx, nrm (k each) | J row chunk | 16 scalars | 8 flags.  Tighter than the generic (n + k)^2 workspace:
@@ -1089,8 +1284,55 @@ size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
   return (bytes + 15) & ~(size_t)15;
 }
 
+// The LDS-resident kernel takes n + k <= 192 (the register-distributed factorisation: 16 x 16 threads x 12 x 12 blocks) whose workspace
+// fits the 160 KiB of a CU; everything beyond runs with H in a global workspace (LARGE).
+bool generic_needs_large(const KernelArgs& a, int elem_size) { return a.n + a.k > 192 || generic_lds_bytes(a, elem_size) > 160 * 1024; }
+size_t generic_large_lds_bytes(const KernelArgs& a, int elem_size) {
+  if (panel_cols_for(a.n, a.k, a.m, a.m_r, elem_size) == 0) return (size_t)1 << 30;   // not even the vectors and an 8-column panel fit
+  const size_t e = elem_size == 8 ? ws_elems_large<double>(a.n, a.k, a.m, a.m_r) : ws_elems_large<float>(a.n, a.k, a.m, a.m_r);
+  return (e * elem_size + (size_t)(a.m + 8) * sizeof(int) + 15) & ~(size_t)15;
+}
+size_t generic_large_workspace_elems(const KernelArgs& a) { const size_t P = (size_t)a.n + a.k; return P * (size_t)large_ld((int)P); }
+int generic_large_grid(const KernelArgs& a, int elem_size, int num_cus) {
+  const size_t lds = generic_large_lds_bytes(a, elem_size);
+  int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  return num_cus * per_cu;
+}
+
+static hipError_t launch_generic_large(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
+  const int elem = dtype == MO_F64 ? 8 : 4;
+  const size_t lds = generic_large_lds_bytes(a, elem);
+  if (lds > 160 * 1024 || !a.H_work) return hipErrorInvalidValue;
+  long long grid = generic_large_grid(a, elem, num_cus);
+  if (grid > a.batch) grid = a.batch;
+  if (grid < 1) grid = 1;
+  hipError_t e = hipSuccess;
+#define MO_LAUNCH_LARGE(TYPE, MODE_)                                                                                                     \
+  do {                                                                                                                                  \
+    e = hipFuncSetAttribute((const void*)kkt_generic_kernel<TYPE, MODE_, 16, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                                      \
+    hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_, 16, 6, true>), dim3((unsigned)grid), dim3(256), lds, stream, a);                 \
+  } while (0)
+#define MO_DISPATCH_LARGE(TYPE)                                       \
+  switch (a.mode) {                                                   \
+    case MODE_LINEARIZE: MO_LAUNCH_LARGE(TYPE, MODE_LINEARIZE); break; \
+    case MODE_RESIDUAL: MO_LAUNCH_LARGE(TYPE, MODE_RESIDUAL); break;   \
+    case MODE_STEP: MO_LAUNCH_LARGE(TYPE, MODE_STEP); break;           \
+    case MODE_ITERATE: MO_LAUNCH_LARGE(TYPE, MODE_ITERATE); break;     \
+    case MODE_SOLVE: MO_LAUNCH_LARGE(TYPE, MODE_SOLVE); break;         \
+    default: return hipErrorInvalidValue;                             \
+  }
+  if (dtype == MO_F64) { MO_DISPATCH_LARGE(double) } else { MO_DISPATCH_LARGE(float) }
+#undef MO_DISPATCH_LARGE
+#undef MO_LAUNCH_LARGE
+  return hipGetLastError();
+}
+
 hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
   const int elem = dtype == MO_F64 ? 8 : 4;
+  if (generic_needs_large(a, elem)) return launch_generic_large(a, dtype, num_cus, stream);
   const size_t lds = generic_lds_bytes(a, elem);
   static const int env_threads = [] { const char* e = getenv("MO_GENERIC_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob
   int threads = (a.n + a.k <= 48) ? 64 : kMaxThreads;  // measured: cfg 2 (P = 36) 8.5 M vs 6.8 M steps/s, cfg 3 (P = 72) 0.75 M vs 1.9 M

@@ -39,6 +39,8 @@ struct mo_plan {
   // scratch for mo_qp_solve with J-level input: G [max_batch][n*n], c [max_batch][n]
   void* G_scratch;
   void* c_scratch;
+  void* H_work;        // generic kernel beyond its LDS-resident range: H workspaces of the persistent grid's workgroups
+  size_t H_work_bytes;
   void* tile_scratch;  // fused Solve: per wave slot of the persistent grid, the G tiles a wave cannot park in LDS between passes
   unsigned long long* ticket;  // device work counter of the fused kernels (zeroed on the stream before each launch)
 };
@@ -120,10 +122,20 @@ int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice 
   } else if (choice == KERNEL_FUSED_F32) {
     MO_HIP_CHECK(mo::launch_fused_f32(a, plan->num_cus, s));
   } else {
-    const size_t need = mo::generic_lds_bytes(a, plan->elem);
-    if (need > 160 * 1024)
-      return fail(MO_ERR_UNSUPPORTED, "this call needs the generic kernel (mode %d, flags 0x%x, layout or alignment outside the fused kernels' range) "
-                  "but the problem needs %zu B of LDS there (> 160 KiB)", a.mode, a.flags, need);
+    if (mo::generic_needs_large(a, plan->elem)) {  // H in a global workspace per workgroup (lazily allocated, plan-owned)
+      const size_t need = mo::generic_large_lds_bytes(a, plan->elem);
+      if (need > 160 * 1024)
+        return fail(MO_ERR_UNSUPPORTED, "n = %d, k = %d, m = %d: not even the state / residual vectors of one problem fit the 160 KiB of LDS", a.n, a.k, a.m);
+      const size_t per_wg = mo::generic_large_workspace_elems(a);
+      const size_t bytes = (size_t)mo::generic_large_grid(a, plan->elem, plan->num_cus) * per_wg * plan->elem;
+      mo_plan* mp = const_cast<mo_plan*>(plan);
+      if (!mp->H_work || mp->H_work_bytes < bytes) {
+        if (mp->H_work) { MO_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(mp->H_work); mp->H_work = nullptr; }
+        if (hipMalloc(&mp->H_work, bytes) != hipSuccess) { mp->H_work = nullptr; (void)hipGetLastError(); return fail(MO_ERR_HIP, "hipMalloc of the %zu B workspace of H failed", bytes); }
+        mp->H_work_bytes = bytes;
+      }
+      a.H_work = mp->H_work; a.H_work_stride = (long long)per_wg;
+    }
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
   return MO_OK;
@@ -196,7 +208,6 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
     return fail(MO_ERR_DIMENSION, "bad dimensions n=%d k=%d m=%d m_r=%d", desc->n, desc->k, desc->m, desc->m_r);
   if (desc->dtype != MO_F64 && desc->dtype != MO_F32) return fail(MO_ERR_UNSUPPORTED, "unknown dtype %d", desc->dtype);
   if (desc->max_batch < 0) return fail(MO_ERR_INVALID_ARGUMENT, "max_batch must be >= 0 (got %lld)", (long long)desc->max_batch);
-  if (desc->n + desc->k > 192) return fail(MO_ERR_UNSUPPORTED, "n + k = %d exceeds the LDS-resident limit of 192", desc->n + desc->k);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MO_ERR_NO_DEVICE, "no HIP device available (the HIP path has no CPU fallback)");
@@ -212,6 +223,8 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   p->G_scratch = nullptr;
   p->c_scratch = nullptr;
   p->tile_scratch = nullptr;
+  p->H_work = nullptr;
+  p->H_work_bytes = 0;
   p->ticket = nullptr;
   if (hipMalloc((void**)&p->ticket, 256) != hipSuccess) {
     delete p;
@@ -222,12 +235,12 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   a.n = desc->n; a.k = desc->k; a.m = desc->m; a.m_r = desc->m_r;
   p->generic_lds = mo::generic_lds_bytes(a, p->elem);
   // fp64 systems up to n = 128 (k <= 31, m <= 256) run on the fused kernels even when the LDS-resident generic kernel cannot hold them
-  const bool fused_capable = desc->dtype == MO_F64 && desc->n <= 128 && desc->k <= 31 && desc->m <= 256;
-  if (p->generic_lds > 160 * 1024 && !fused_capable) {
-    const size_t need = p->generic_lds;
+  // Any size Setup accepts (qp.cc:36-48 resizes to any N, K): beyond the fused kernels and the LDS-resident generic kernel (n + k <= 192,
+  // H in LDS) the generic kernel keeps H in a global workspace; only a problem whose state / residual vectors alone exceed the LDS is refused.
+  if (mo::generic_needs_large(a, p->elem) && mo::generic_large_lds_bytes(a, p->elem) > 160 * 1024) {
     (void)hipFree(p->ticket);
     delete p;
-    return fail(MO_ERR_UNSUPPORTED, "problem needs %zu B of LDS (> 160 KiB)", need);
+    return fail(MO_ERR_UNSUPPORTED, "n = %d, k = %d, m = %d: the state / residual vectors of one problem exceed the 160 KiB of LDS", desc->n, desc->k, desc->m);
   }
   *out = p;
   return MO_OK;
@@ -238,6 +251,7 @@ int mo_plan_destroy(mo_plan* plan) {
   if (plan->G_scratch) (void)hipFree(plan->G_scratch);
   if (plan->c_scratch) (void)hipFree(plan->c_scratch);
   if (plan->tile_scratch) (void)hipFree(plan->tile_scratch);
+  if (plan->H_work) (void)hipFree(plan->H_work);
   if (plan->ticket) (void)hipFree(plan->ticket);
   delete plan;
   return MO_OK;

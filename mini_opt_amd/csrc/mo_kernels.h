@@ -57,6 +57,8 @@ struct KernelArgs {
   int stagger;     // fused step kernel: start offset between the waves that share a SIMD, in units of 127 x 64 cycles (set by launch_fused)
   int chain_prio;  // fused step kernel: s_setprio 1 while a wave is in the elimination / substitution chains
   int no_tiny;     // MO_PLAN_NO_TINY: keep n + k <= 15 on the 32-variable tile grid (set by mo_api.hip from the plan flags)
+  // generic kernel beyond its LDS-resident range: P x ldh workspace of H per workgroup of the persistent grid (plan-owned)
+  void* H_work; long long H_work_stride;
   // diagnostics only (tools/phase_timer.hip builds kkt_fused.hip with MO_FUSED_STAMPS); NULL in the product
   unsigned long long* debug;
 };
@@ -64,6 +66,11 @@ struct KernelArgs {
 // shape-generic LDS kernel (any n,k,m,m_r that fits LDS), kkt_generic.hip
 size_t generic_lds_bytes(const KernelArgs& a, int elem_size);
 hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
+// beyond n + k = 192 or the 160 KiB of LDS the generic kernel keeps H in a global workspace (blocked LDL^T, kkt_generic.hip "LARGE")
+bool generic_needs_large(const KernelArgs& a, int elem_size);
+size_t generic_large_lds_bytes(const KernelArgs& a, int elem_size);   // > 160 KiB: not even the vectors fit
+size_t generic_large_workspace_elems(const KernelArgs& a);            // per workgroup
+int generic_large_grid(const KernelArgs& a, int elem_size, int num_cus);
 // QPNullSpaceSolver::Solve (qp.cc:679-729): pivoted Householder QR of A_eq^T, reduced Hessian, LLT; x -> a.delta, status -> a.status
 hipError_t launch_nullspace(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
 size_t nullspace_lds_bytes(int n, int k, int m_r, int elem_size);

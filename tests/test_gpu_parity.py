@@ -1084,9 +1084,9 @@ def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
     assert agree >= B - 1
 
 
-def test_large_fp64_plan_falls_back_cleanly():
-    """n = 128, k = 14 in fp64 does not fit the LDS-resident generic kernel: calls the fused kernels cannot serve return
-    MO_ERR_UNSUPPORTED with a message instead of launching; the fused-capable calls work."""
+def test_large_fp64_plan_runs_on_both_kernel_families():
+    """n = 128, k = 14 in fp64 does not fit the LDS-resident generic kernel (H alone is 161 KB): the fused kernels serve it, and a call that is
+    forced onto the generic kernel now runs there too with H in its global workspace (it used to return MO_ERR_UNSUPPORTED)."""
     rng = np.random.default_rng(1)
     n, k, m, m_r, B = 128, 14, 4, 256, 3
     J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
@@ -1098,15 +1098,99 @@ def test_large_fp64_plan_falls_back_cleanly():
     s.SetVariables(T(vars_))
     delta, alpha, status = s.NewtonStep(0.1, 0.995)
     assert torch.all(status == 0) and torch.isfinite(delta).all()
+    delta = delta.clone()
     d0, a0, st0 = s.NewtonStep(0.1, 0.995, include_inequalities=False)   # MO_STEP_NO_INEQUALITIES and the KKT residual run fused as well
     assert torch.all(st0 == 0) and torch.isfinite(d0).all() and torch.all(a0 == 1.0)
     r_, kkt = s.EvaluateKKTConditions(0.1)
     assert torch.isfinite(r_).all() and torch.isfinite(kkt).all()
-    with pytest.raises(L.MiniOptError) as e:
-        Q.QPInteriorPointSolver(prob, force_generic=True).NewtonStep(0.1, 0.995)
-    assert "LDS" in str(e.value)
-    G, c, half = Q.linearize(prob)                                   # n = 128 alone still fits the generic kernel (k = m = 0 there)
+    sg = Q.QPInteriorPointSolver(prob, force_generic=True)
+    assert sg.step_kernel() == "generic"
+    sg.SetVariables(T(vars_))
+    dg, ag, stg = sg.NewtonStep(0.1, 0.995)
+    assert torch.all(stg == 0)
+    assert rel_inf_rows(dg.cpu().numpy(), delta.cpu().numpy()).max() < 1e-10
+    np.testing.assert_allclose(ag.cpu().numpy(), alpha.cpu().numpy(), atol=1e-10)
+    G, c, half = Q.linearize(prob)
     np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,k,m,m_r,level,dt", [(256, 40, 128, 300, "J", torch.float64), (256, 40, 128, 0, "QP", torch.float64), (200, 0, 30, 210, "J", torch.float64),
+                                                (160, 50, 0, 170, "J", torch.float64), (300, 20, 64, 310, "J", torch.float32), (130, 70, 17, 0, "QP", torch.float64)],
+                         ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP"])
+def test_sizes_beyond_every_lds_resident_kernel(n, k, m, m_r, level, dt):
+    """The reference resizes its solver to any N, K (qp.cc:36-48).  Beyond the fused kernels (n <= 128, k <= 31) and the LDS-resident generic
+    kernel (n + k <= 192, H in LDS) the generic kernel keeps H in a global workspace of its workgroup: blocked right-looking LDL^T (column
+    panels staged in LDS, rank-32 trailing updates), 96-wide J^T J super-blocks.  Step (with and without inequalities), KKT residual,
+    Iterate and the whole Solve against the oracle: directions within 1e-10 rel-inf, Solve iteration-exact (fp32: against the oracle on
+    fp32-rounded inputs at fp32 tolerances)."""
+    rng = np.random.default_rng(n + 7 * k + m)
+    B = 3
+    f64 = dt == torch.float64
+    f = (lambda a_: a_) if f64 else (lambda a_: a_.astype(np.float32).astype(np.float64))
+    mr = m_r if m_r else n + 20
+    J = f(rng.uniform(-1, 1, (B, mr, n))); r = f(rng.uniform(-1, 1, (B, mr)))
+    A = f(rng.uniform(-1, 1, (B, n, k)))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m))
+    x0 = rng.uniform(-0.5, 0.5, (B, n)); b = f(-np.einsum("bik,bi->bk", A, x0))
+    cb = f(-ca * np.take_along_axis(x0, cv.astype(np.int64), axis=1) + rng.uniform(0.05, 0.5, (B, m)))
+    lam = float(np.float32(0.05))
+    G = f(np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)); c = f(np.einsum("bqi,bq->bi", J, r))
+    x = f(rng.uniform(-0.1, 0.1, (B, n))); sl = f(rng.uniform(0.2, 1.5, (B, m))); z = f(rng.uniform(0.1, 2, (B, m))); y = f(rng.uniform(-1, 1, (B, k)))
+    vars_ = np.concatenate([x, sl, y, z], axis=1); mu = np.full(B, float(np.float32(0.05)))
+    common = dict(A_eq=T(A, dt) if k else None, b_eq=T(b, dt) if k else None, cons_var=T(cv, torch.int32) if m else None,
+                  cons_a=T(ca, dt) if m else None, cons_b=T(cb, dt) if m else None)
+    prob = (Q.BatchedQP(n=n, k=k, m=m, J=T(J, dt), r=T(r, dt), lam=lam, **common) if level == "J"
+            else Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1), dt), c=T(c, dt), **common))
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel() == "generic" and s.solve_kernel() == "generic"
+    s.SetVariables(T(vars_, dt))
+    delta, alpha, status = s.NewtonStep(T(mu, dt), 0.995)
+    assert torch.all(status == 0)
+    Gl = np.tril(G) if level == "QP" else np.stack([np.tril(J[p].T @ J[p] + lam * np.eye(n)) for p in range(B)])
+    cl = c if level == "QP" else np.einsum("bqi,bq->bi", J, r)
+    tol = 1e-10 if f64 else TOL32
+    qps = []
+    for p in range(B):
+        qp = orc.QP(G=Gl[p], c=cl[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+        qps.append(qp)
+        o = orc.Solver(qp)
+        st, d_ref, a_ref = o.newton_step(vars_[p], mu[p] if m else 0.0, 0.995, True)
+        assert st == 0
+        got = delta[p].double().cpu().numpy()
+        assert np.abs(got - d_ref).max() / np.abs(d_ref).max() < tol, (p, np.abs(got - d_ref).max() / np.abs(d_ref).max())
+        np.testing.assert_allclose(alpha[p].double().cpu().numpy(), a_ref, atol=1e-9 if f64 else 1e-3)
+        o.variables[:] = vars_[p]
+        o.evaluate_kkt(True)
+        if p == 0:
+            r_dev, kkt_dev = s.EvaluateKKTConditions(T(mu, dt))
+            scale = max(1.0, np.abs(o.r).max())
+            np.testing.assert_allclose(r_dev[0].double().cpu().numpy(), o.r, rtol=0, atol=(1e-11 if f64 else 2e-4) * scale)
+    # Iterate (predictor-corrector) and Solve
+    s.SetVariables(T(vars_, dt))
+    ip, st = s.Iterate(T(mu, dt), Q.PREDICTOR_CORRECTOR if m else Q.COMPLEMENTARITY)
+    assert torch.all(st == 0)
+    after = s.variables().double().cpu().numpy()
+    # (fp32: the residual of a 300-variable system has a rounding floor of ~ eps32 |K| |x| sqrt(n) ~ 3e-3)
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8 if f64 else 1e-2, termination_complementarity_tol=1e-6 if f64 else 1e-2,
+              max_iterations=15, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+    out = s.Solve(Q.Params(**kw))
+    assert torch.all(out.status == 0)
+    v = s.variables().double().cpu().numpy()
+    for p in range(B):
+        o = orc.Solver(qps[p])
+        o.variables[:] = vars_[p]
+        sti, ipr = o.iterate(mu[p], orc.PREDICTOR_CORRECTOR if m else orc.COMPLEMENTARITY)
+        assert sti == 0
+        sc = max(1.0, np.abs(o.variables).max())
+        np.testing.assert_allclose(after[p], o.variables, rtol=0, atol=(1e-8 if f64 else 5e-3) * sc)
+        o2 = orc.Solver(qps[p])
+        term, its = o2.solve(**kw)
+        if f64:
+            assert int(out.termination_state[p]) == term and int(out.num_iterations[p]) == len(its), (p, int(out.num_iterations[p]), len(its))
+            np.testing.assert_allclose(v[p][:n], o2.variables[:n], rtol=0, atol=1e-7 * max(1.0, np.abs(o2.variables[:n]).max()))
+        else:
+            assert int(out.termination_state[p]) == Q.SATISFIED_KKT_TOL and abs(int(out.num_iterations[p]) - len(its)) <= 2
+            assert np.abs(v[p][:n] - o2.variables[:n]).max() <= 2e-2 * max(1.0, np.abs(o2.variables[:n]).max())
 
 
 @pytest.mark.parametrize("n,k,m,dt", [(58, 21, 21, torch.float64), (60, 21, 21, torch.float64), (100, 8, 30, torch.float64), (100, 24, 30, torch.float64),
