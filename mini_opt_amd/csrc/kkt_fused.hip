@@ -275,12 +275,19 @@ __device__ inline const void* uniform_ptr(const void* p) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
   return (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
+// MO_J_NT (A/B builds): the J stream's loads carry the non-temporal hint -- J is read once, by one CU; without the hint it washes the
+// lines other waves re-read every pass (tile park, spills) out of the XCD's L2.
+#ifdef MO_J_NT
+#define MO_J_POLICY " nt"
+#else
+#define MO_J_POLICY ""
+#endif
 template <int IMM> __device__ inline void dma16_s(const void* sbase_in, unsigned voff, unsigned lds_dst_in) {
   const void* sbase = uniform_ptr(sbase_in);
   const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_in);
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4" MO_J_POLICY "\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM)
       : "memory");
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   for (int i = (int)(threadIdx.x & 63); i < N; i += 64) xs[i] = 0.0;
   lds_fence();
 #ifdef MO_FUSED_STAMPS
-  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
   const unsigned long long stamp_t0 = stamp_prev, stamp_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1039,6 +1046,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
       stream.prologue();
     }
+    MO_STAMP(13);   // (diagnostic build) loop top, ticket, addresses, ring fill issued
 
     // ---- P0: every small vector of this problem goes global -> LDS by DMA, issued behind the ring fill; nothing of it sits in
     //          a VGPR while J streams (the tile registers need the room), and the last wait of the stream covers it.
@@ -1061,6 +1069,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       dma_doubles(vp + nn + m_lay, vec_base + (3 * N + 4 * MCAP + MCAP / 2) * 8, k, lane);   // y
       dma_doubles((const double*)ka->b + p * ka->b_stride, vec_base + (3 * N + 4 * MCAP + MCAP / 2 + 16 * NY) * 8, k, lane);  // b_eq
     }
+    MO_STAMP(14);   // (diagnostic build) tile registers zeroed, small-vector DMAs issued
     // tile column NT = [A_eq^T | rhs] (rhs is merged in after P3); y diagonal tile = [0, -b_eq; -b_eq^T, 0]
     load_a_tiles<NT, QPL, NY>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, nn, g, j, U);
 
@@ -1075,6 +1084,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     if (QPL) {
       load_g_tiles<NT, NY>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, nn, g, j, U, cvec);
     } else {
+#ifdef MO_FUSED_STAMPS   // diagnostic build: how long does a wave wait for its FIRST group of J (the latency a cross-problem prefetch could hide)?
+      stream.wait_for_oldest(stream.nsteps - 1);
+      MO_STAMP(7);
+#endif
       stream.run(U, cpart);
 #pragma unroll
       for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
@@ -1276,6 +1289,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
 #ifdef MO_FUSED_STAMPS
   if ((threadIdx.x & 63) == 0 && a.debug) {
     for (int i = 0; i < 8; ++i) atomicAdd(a.debug + i, stamp_acc[i]);
+    atomicAdd(a.debug + 13, stamp_acc[13]); atomicAdd(a.debug + 14, stamp_acc[14]);
     atomicAdd(a.debug + 8, 1ull);
     const unsigned long long life = stamp_prev - stamp_t0, rt = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
     atomicMax(a.debug + 9, life);
@@ -1345,6 +1359,58 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
     const double lam = lam_in > 0.0 ? lam_in : 0.0;  // nonlinear.cc:187-189
     double* Go = (double*)a.G_out + p * a.G_out_stride;
     const int ld = a.G_out_ld;
+    // Whole-line stores.  The tile layout scatters G: a lane's four registers are four rows two apart, the lanes of a row are columns two
+    // apart, and two tiles interleave in every 32 natural indices.  The 2 x 2 tiles (2 sa + p, 2 sb + q) together ARE the natural block
+    // rows [32 sa, +32) x columns [32 sb, +32): each is staged through the (idle) ring as the 32 x 32 block of the LOWER triangle it belongs
+    // to, column-major, and leaves as eight 16-byte-per-lane stores -- every 128-byte line of G written whole, once; the strict upper
+    // blocks go out as zeros the same way.  (n on the tile grid and a 16-byte aligned G; anything else takes the element-wise path below.)
+    const bool whole_lines = NT <= 6 && nn == 16 * NT && !(ld & 1) && !(a.G_out_stride & 1) && (((uintptr_t)a.G_out & 15) == 0);
+    if (whole_lines) {   // (NT <= 6: the 128 grid keeps the element-wise path, it has no registers left for a second store sequence)
+      double* const stage = reinterpret_cast<double*>(smem);
+      static_assert(D * SLOT >= 32 * 32 * 8, "the ring holds one 32 x 32 block");
+#pragma unroll
+      for (int sa = 0; sa < NT / 2; ++sa) {
+#pragma unroll
+        for (int sb = sa; sb < NT / 2; ++sb) {
+          if (sa == sb) {
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {                       // tiles (2 sa + pq, 2 sa + pq): rows and columns of one parity, both triangles present
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int natr = 2 * (g + 4 * t) + pq, natc = 2 * j + pq;
+                const double v = U[(2 * sa + pq) * NB + 2 * sa + pq][t] + (natr == natc ? lam : 0.0);
+                stage[natr + 32 * natc] = natr >= natc ? v : 0.0;
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                          // tile (2 sa, 2 sa + 1): even rows x odd columns; its mirror image is not stored
+              const int natr = 2 * (g + 4 * t), natc = 2 * j + 1;
+              const int hi = natr > natc ? natr : natc, lo = natr > natc ? natc : natr;
+              stage[hi + 32 * lo] = U[(2 * sa) * NB + 2 * sa + 1][t];
+              stage[lo + 32 * hi] = 0.0;
+            }
+          } else {
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {                       // G(32 sa + natr, 32 sb + natc) lies above the diagonal: it is G(row natc, column natr) of the lower block
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int natr = 2 * (g + 4 * t) + (pq >> 1), natc = 2 * j + (pq & 1);
+                stage[natc + 32 * natr] = U[(2 * sa + (pq >> 1)) * NB + 2 * sb + (pq & 1)][t];
+              }
+            }
+          }
+          lds_fence();
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const d2 v = *(const d2*)(stage + it * 128 + lane * 2);
+            const int col = it * 4 + (lane >> 4), row = (lane & 15) * 2;
+            *(d2*)(Go + (32 * sb + row) + (size_t)(32 * sa + col) * ld) = v;
+            if (sa != sb) *(d2*)(Go + (32 * sa + row) + (size_t)(32 * sb + col) * ld) = d2{0.0, 0.0};   // the strict upper triangle stays exactly zero
+          }
+          lds_fence();
+        }
+      }
+    } else {
 #pragma unroll
     for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
@@ -1361,6 +1427,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
           }
         }
       }
+    }
     }
     if (g == 0) stv_n<NT, false>((double*)a.c_out + p * a.c_out_stride, j, nn, cvec);
     if (lane == 0 && a.half_sq_out) ((double*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = half_sq;

@@ -208,6 +208,16 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
     return fail(MO_ERR_DIMENSION, "bad dimensions n=%d k=%d m=%d m_r=%d", desc->n, desc->k, desc->m, desc->m_r);
   if (desc->dtype != MO_F64 && desc->dtype != MO_F32) return fail(MO_ERR_UNSUPPORTED, "unknown dtype %d", desc->dtype);
   if (desc->max_batch < 0) return fail(MO_ERR_INVALID_ARGUMENT, "max_batch must be >= 0 (got %lld)", (long long)desc->max_batch);
+  {
+    // Any size Setup accepts (qp.cc:36-48 resizes to any N, K): beyond the fused kernels and the LDS-resident generic kernel (n + k <= 192,
+    // H in LDS) the generic kernel keeps H in a global workspace; only a problem whose state / residual vectors alone exceed the LDS is refused.
+    mo::KernelArgs sz;
+    memset(&sz, 0, sizeof(sz));
+    sz.n = desc->n; sz.k = desc->k; sz.m = desc->m; sz.m_r = desc->m_r;
+    const int elem = desc->dtype == MO_F64 ? 8 : 4;
+    if (mo::generic_needs_large(sz, elem) && mo::generic_large_lds_bytes(sz, elem) > 160 * 1024)
+      return fail(MO_ERR_UNSUPPORTED, "n = %d, k = %d, m = %d: the state / residual vectors of one problem exceed the 160 KiB of LDS", desc->n, desc->k, desc->m);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MO_ERR_NO_DEVICE, "no HIP device available (the HIP path has no CPU fallback)");
@@ -235,13 +245,7 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   a.n = desc->n; a.k = desc->k; a.m = desc->m; a.m_r = desc->m_r;
   p->generic_lds = mo::generic_lds_bytes(a, p->elem);
   // fp64 systems up to n = 128 (k <= 31, m <= 256) run on the fused kernels even when the LDS-resident generic kernel cannot hold them
-  // Any size Setup accepts (qp.cc:36-48 resizes to any N, K): beyond the fused kernels and the LDS-resident generic kernel (n + k <= 192,
-  // H in LDS) the generic kernel keeps H in a global workspace; only a problem whose state / residual vectors alone exceed the LDS is refused.
-  if (mo::generic_needs_large(a, p->elem) && mo::generic_large_lds_bytes(a, p->elem) > 160 * 1024) {
-    (void)hipFree(p->ticket);
-    delete p;
-    return fail(MO_ERR_UNSUPPORTED, "n = %d, k = %d, m = %d: the state / residual vectors of one problem exceed the 160 KiB of LDS", desc->n, desc->k, desc->m);
-  }
+
   *out = p;
   return MO_OK;
 }

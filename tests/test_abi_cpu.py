@@ -46,8 +46,13 @@ def test_argument_errors_without_gpu(lib):
     bad = L.PlanDesc(0, 0, 0, 0, L.MO_F64, 0, 0, 0, 1)
     assert lib.mo_plan_create(C.byref(bad), C.byref(plan)) == -2
     assert b"bad dimensions" in lib.mo_last_error()
-    big = L.PlanDesc(512, 0, 0, 0, L.MO_F64, 0, 0, 0, 1)
+    big = L.PlanDesc(20000, 0, 0, 0, L.MO_F64, 0, 0, 0, 1)            # the state / residual vectors alone exceed the LDS: refused before any device query
     assert lib.mo_plan_create(C.byref(big), C.byref(plan)) == -3
+    assert b"LDS" in lib.mo_last_error()
+    sizeable = L.PlanDesc(512, 40, 128, 0, L.MO_F64, 0, 0, 0, 1)       # beyond every LDS-resident kernel, served with H in a global workspace: not a size error
+    assert lib.mo_plan_create(C.byref(sizeable), C.byref(plan)) != -3
+    if plan.value:
+        lib.mo_plan_destroy(plan)
     assert lib.mo_newton_step(None, None, 0, None, 0, None, 0, 0.995, 0, None, 0, None, None, None) == -1
 
 
@@ -118,3 +123,18 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), cname
         for f in fields:
             assert int(out[f"{cname}.{f}"]) == getattr(cls, rename.get(f, f)).offset, (cname, f)
+
+
+def test_isa_lint_flags_the_copy_in_front_of_an_exec_restore():
+    """tools/isa_lint.py on a fixture of OUR OWN compiler output (tests/golden/isa_defect_block.s: the loop-exit block of the pre-fix generic
+    Solve kernel whose `v_accvgpr_write_b32 a85, v166` runs with EXEC = 0) and on the same block with the copy behind
+    the restore."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = open(os.path.join(ROOT, "tests", "golden", "isa_defect_block.s")).read()
+    hits = lint.lint_text(bad)
+    assert len(hits) == 1 and "v_accvgpr_write_b32 a85, v166" in hits[0][3]
+    good = bad.replace("\tv_accvgpr_write_b32 a85, v166\n", "").replace("\ts_or_b64 exec, exec, s[0:1]\n", "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a85, v166\n")
+    assert "v_accvgpr_write_b32" in good and lint.lint_text(good) == []

@@ -1172,7 +1172,7 @@ def test_sizes_beyond_every_lds_resident_kernel(n, k, m, m_r, level, dt):
     after = s.variables().double().cpu().numpy()
     # (fp32: the residual of a 300-variable system has a rounding floor of ~ eps32 |K| |x| sqrt(n) ~ 3e-3)
     kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8 if f64 else 1e-2, termination_complementarity_tol=1e-6 if f64 else 1e-2,
-              max_iterations=15, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+              max_iterations=15 if f64 else 25, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
     out = s.Solve(Q.Params(**kw))
     assert torch.all(out.status == 0)
     v = s.variables().double().cpu().numpy()

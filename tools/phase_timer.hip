@@ -65,11 +65,15 @@ int main(int argc, char** argv) {
     std::vector<int> st(batch); CK(hipMemcpy(st.data(), status, batch * 4, hipMemcpyDeviceToHost));
     size_t okc = 0; for (size_t i = 0; i < batch; ++i) okc += st[i] == 0;
     if (rep < 2) continue;
-    const char* names[7] = {"P0 small loads + tile init", "P1 J stream + J^T J MFMA", "P3/P2/P4 constraints, rhs", "P5 diagonal sweeps",
-                            "P5 panel + trailing MFMA", "P6 backward", "P7 epilogue"};
-    double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)h[i];
+    const char* names[8] = {"P0 small loads + tile init", "P1 J stream + J^T J MFMA", "P3/P2/P4 constraints, rhs", "P5 diagonal sweeps",
+                            "P5 panel + trailing MFMA", "P6 backward", "P7 epilogue", "P1a wait for the FIRST J group"};
+    double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[i];
     printf("n=%d batch=%zu: %.3f ms (%.2f M steps/s, stamped build), status ok %zu/%zu, waves %llu\n", n, batch, ms, batch / ms / 1e3, okc, batch, h[8]);
-    for (int i = 0; i < 7; ++i) printf("  %-30s %9.0f ticks/problem/wave  %5.1f %%\n", names[i], (double)h[i] / batch, 100.0 * h[i] / tot);
+    tot += (double)h[13] + (double)h[14];
+    for (int i = 0; i < 8; ++i) printf("  %-30s %9.0f ticks/problem/wave  %5.1f %%\n", names[i], (double)h[i] / batch, 100.0 * h[i] / tot);
+    printf("  %-30s %9.0f ticks/problem/wave  %5.1f %%\n", "P0a loop top, ticket, ring fill", (double)h[13] / batch, 100.0 * h[13] / tot);
+    printf("  %-30s %9.0f ticks/problem/wave  %5.1f %%\n", "P0b tile zeroing, vector DMAs", (double)h[14] / batch, 100.0 * h[14] / tot);
+    printf("  (P0 above is what is left of it: the [A_eq^T] tile loads)\n");
     printf("  wave lifetime: max %llu min %llu cycles; mean realtime %.1f us, max %.1f us (100 MHz ticks) => shader clock %.2f GHz\n", h[9], h[10],
            h[11] / (double)h[8] / 100.0, h[12] / 100.0, (tot / h[8]) / (h[11] / (double)h[8] / 100.0) / 1e3);
     printf("  total %.0f ticks per problem per wave (s_memtime ticks: 100 MHz constant clock => x ~21 for core cycles)\n", tot / batch);
