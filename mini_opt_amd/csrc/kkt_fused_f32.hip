@@ -1110,9 +1110,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
   using C = SolveCfg32<NT>;
   constexpr int N = C::N, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
   constexpr int WAVES = 4 * WPS;
-  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * D * SLOT];
+  constexpr int WAVE_LDS = D * SLOT > 8192 ? D * SLOT : 8192;   // the ring; after the stream: a 64 x 32 staging block of G (see below)
+  __shared__ __attribute__((aligned(16))) char smem_all[WAVES * WAVE_LDS];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  char* const smem = smem_all + wave * D * SLOT;
+  char* const smem = smem_all + wave * WAVE_LDS;
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
   const int nsteps = a.m_r >> 2;
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
@@ -1196,6 +1197,57 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
     const float lam = lam_in > 0.0f ? lam_in : 0.0f;  // nonlinear.cc:187-189
     float* Go = (float*)a.G_out + p * a.G_out_stride;
     const int ld = a.G_out_ld;
+    // Whole-line stores (as the fp64 kernel's): the 4 x 4 tiles (4 sa + p, 4 sb + q) ARE the natural block rows [64 sa, +64) x columns
+    // [64 sb, +64) (position i of tile c is variable 4 i + (c & 3) of its 64).  Each natural block of the LOWER triangle is staged
+    // through the idle ring in two halves of 32 columns (64 x 32 floats = 8 KB, column-major) and leaves as eight 16-byte-per-lane
+    // stores, every line of G written whole; the strict upper blocks go out as zeros the same way.
+    const bool whole_lines = !(ld & 3) && !(a.G_out_stride & 3) && (((uintptr_t)a.G_out & 15) == 0);
+    if (whole_lines) {
+      float* const stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int sa = 0; sa < NT / 4; ++sa) {
+#pragma unroll
+        for (int sb = sa; sb < NT / 4; ++sb) {
+#pragma unroll 1
+          for (int half = 0; half < 2; ++half) {   // (a runtime loop: it indexes no tile register, and unrolling it doubles the code for nothing)
+            // Two lane bases carry every staging address, the rest are immediates: element (row natr = 16 g + 4 t + p, column natc = 4 j + q)
+            // sits at  natr + 64 (natc & 31) = LA + 4 t + p + 64 q  when staged as it is (columns of this half: lanes with j >> 3 == half)
+            // and at   natc + 64 (natr & 31) = LB + q + 64 (4 t + p) when staged transposed (lanes with g >> 1 == half).
+            const int LA = 16 * g + 256 * (j & 7), LB = 4 * j + 1024 * (g & 1);
+            const bool in_a = (j >> 3) == half, in_b = (g >> 1) == half;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+              for (int qq = (sa == sb ? pp : 0); qq < 4; ++qq) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  const float v = U[(4 * sa + pp) * NT + 4 * sb + qq][t];
+                  const int natr = 16 * g + 4 * t + pp, natc = 4 * j + qq;      // inside their 64-blocks
+                  if (sa != sb) {                 // above the diagonal: G(row natc, column natr) of the lower block
+                    if (in_b) stage[LB + qq + 64 * (4 * t + pp)] = v;
+                  } else if (pp == qq) {          // a symmetric tile: both triangles present
+                    if (in_a) stage[LA + 4 * t + pp + 64 * qq] = natr >= natc ? v + (natr == natc ? lam : 0.0f) : 0.0f;
+                  } else {                        // its mirror image is not stored: the value goes below the diagonal, a zero above
+                    if (in_a) stage[LA + 4 * t + pp + 64 * qq] = natr > natc ? v : 0.0f;
+                    if (in_b) stage[LB + qq + 64 * (4 * t + pp)] = natr > natc ? 0.0f : v;
+                  }
+                }
+              }
+            }
+            lds_fence32();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const int e = it * 256 + lane * 4;
+              const f4 v = *(const f4*)(stage + e);
+              const int col = 32 * half + (e >> 6), row = e & 63;
+              *(f4*)(Go + (64 * sb + row) + (size_t)(64 * sa + col) * ld) = v;
+              if (sa != sb) *(f4*)(Go + (64 * sa + row) + (size_t)(64 * sb + col) * ld) = f4{0.0f, 0.0f, 0.0f, 0.0f};   // strict upper triangle: exactly zero
+            }
+            lds_fence32();
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
@@ -1209,6 +1261,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
           if (hi != lo) Go[lo + (size_t)hi * ld] = 0.0f;                             // the strict upper triangle stays exactly zero
         }
       }
+    }
     }
     float cvec[NT];
 #pragma unroll
