@@ -82,11 +82,24 @@ template <int CTRL> __device__ inline double dpp_f64(double v) {
 }
 // Sum / min over the 16 lanes of each row, result in every lane of the row.  DPP only (no LDS crossbar):
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+// MO_ROWSUM_SWIZZLE (A/B builds): the same butterfly (bit-identical sums) through ds_swizzle_b32 -- the exchange goes over the LDS crossbar
+// (two LDS-pipe instructions per step) and only the four adds stay on the VALU: 4 instead of 12 VALU instructions per row sum.
+template <int PATTERN> __device__ inline double swizzle_f64(double v) {
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline double row_sum(double v) {
+#ifdef MO_ROWSUM_SWIZZLE
+  v += swizzle_f64<0x041F>(v);   // bit mode: lane ^ 1
+  v += swizzle_f64<0x081F>(v);   // lane ^ 2
+  v += swizzle_f64<0x101F>(v);   // lane ^ 4
+  v += swizzle_f64<0x201F>(v);   // lane ^ 8
+#else
   v += dpp_f64<0xB1>(v);
   v += dpp_f64<0x4E>(v);
   v += dpp_f64<0x141>(v);
   v += dpp_f64<0x140>(v);
+#endif
   return v;
 }
 __device__ inline double row_min(double v) {
@@ -360,6 +373,15 @@ __device__ inline void sweep_step(d4& T, bool& ok, int g, int j) {
     T[t] = nv;
   }
 }
+// Pad behind an EXEC-masked VALU write inside an asm block.  What the next instruction may need: a DPP read of the VGPR just written
+// (2 wait states: the s_mov_b64 that restores EXEC is one, `s_nop 0` the other).  The 5 wait states of "EXEC written -> DPP" apply to
+// VALU writes of EXEC (v_cmpx) only; an s_mov to EXEC is interlocked by the hardware (hipcc itself puts DPP ops right behind
+// s_or_b64 exec).  Rounds 1-2 padded with `s_nop 4`; A/B builds restore that with -DMO_MASKED_PAD_4.
+#ifdef MO_MASKED_PAD_4
+#define MO_MASKED_PAD "4"
+#else
+#define MO_MASKED_PAD "0"
+#endif
 // 64-bit helpers for the lean sweep (SW == 3): one v_mov_b64_dpp instead of two 32-bit DPP movs, and EXEC-masked v_mov_b64
 // instead of v_cndmask_b32 pairs.  The asm blocks restore EXEC and end with the wait states a following DPP op needs.
 template <int LANE_IN_ROW> __device__ inline double row_bcast64(double v) {
@@ -370,14 +392,14 @@ template <int LANE_IN_ROW> __device__ inline double row_bcast64(double v) {
 template <unsigned long long MASK> __device__ inline void masked_set(double& dst, double src) {  // dst = src in the lanes of MASK
   unsigned long long save;
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b64 %[d], %[s]\n\t"
-               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               "s_mov_b64 exec, %[sv]\n\ts_nop " MO_MASKED_PAD
                : [d] "+v"(dst), [sv] "=&s"(save)
                : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
 template <unsigned long long MASK> __device__ inline void masked_set_neg(double& dst, double src) {  // dst = -src in the lanes of MASK
   unsigned long long save;  // v_max_f64 with both operands negated: the negation rides on the source modifiers (no xor + mov)
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_max_f64 %[d], -%[s], -%[s]\n\t"
-               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               "s_mov_b64 exec, %[sv]\n\ts_nop " MO_MASKED_PAD
                : [d] "+v"(dst), [sv] "=&s"(save)
                : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
@@ -386,7 +408,7 @@ template <unsigned long long MASK> __device__ inline void masked_zero4(d4& T) { 
   double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
   asm volatile(
       "s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b64 %[a], 0\n\tv_mov_b64 %[b], 0\n\t"
-      "v_mov_b64 %[c], 0\n\tv_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+      "v_mov_b64 %[c], 0\n\tv_mov_b64 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop " MO_MASKED_PAD
       : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3), [sv] "=&s"(save)
       : [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
   T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
@@ -404,7 +426,11 @@ __device__ inline void sweep_step_lean(d4& T, double& bad, int g, int j) {
   double inv = __builtin_amdgcn_rcp(d);
   inv = fma(inv, fma(-d, inv, 1.0), inv);  // one Newton step: |inv d - 1| < 2e-15 (tools/microbench.hip)
   asm volatile("v_fma_f64 %0, %1, 0, %0" : "+v"(bad) : "v"(inv));  // volatile: hipcc would sink sixteen of these to the end
+#ifdef MO_SWEEP_VALU_ROW   // A/B builds: the row broadcast on the VALU (four v_permlane swaps) instead of over the LDS crossbar (two ds_bpermute)
+  double rk = bcast_from_row<src_g>(rowreg) * inv;
+#else
   double rk = bpermute_f64((16 * src_g + j) * 4, rowreg) * inv;  // T(k, j) / d for this lane's column j, in every row
+#endif
   masked_set_neg<mcol>(rk, inv);
   double f[4];
 #pragma unroll
@@ -426,7 +452,7 @@ __device__ inline void sweep_step_lean(d4& T, double& bad, int g, int j) {
 template <unsigned long long MASK> __device__ inline void masked_zero1(double& v) {  // v = 0 in the lanes of MASK
   unsigned long long save;
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b64 %[d], 0\n\t"
-               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               "s_mov_b64 exec, %[sv]\n\ts_nop " MO_MASKED_PAD
                : [d] "+v"(v), [sv] "=&s"(save)
                : [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
@@ -435,7 +461,7 @@ template <unsigned long long MASK> __device__ inline void masked_mul4(d4& T, dou
   double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
   asm volatile(
       "s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mul_f64 %[a], %[a], %[f]\n\tv_mul_f64 %[b], %[b], %[f]\n\t"
-      "v_mul_f64 %[c], %[c], %[f]\n\tv_mul_f64 %[d], %[d], %[f]\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+      "v_mul_f64 %[c], %[c], %[f]\n\tv_mul_f64 %[d], %[d], %[f]\n\ts_mov_b64 exec, %[sv]\n\ts_nop " MO_MASKED_PAD
       : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3), [sv] "=&s"(save)
       : [f] "v"(f), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
   T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
@@ -1836,40 +1862,41 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       if (!guess_pass && !iterate_mode) {
         // ---- the decision point of Solve (qp.cc:116-147)
-        if (it > 0) {
-          double kf[4];
+        const bool have_prev = it > 0;
+        bool stop = false;
+        double kf[4] = {0.0, 0.0, 0.0, 0.0};
+        if (have_prev) {
           kkt_errors_sq(mu_used, kf);                               // kkt_after of the previous iteration (squared), qp.cc:127
           const double cur_mu = n_rc1 * inv_m;                      // ComputeMu, qp.cc:509-516 (one f64 division per kernel, not per pass)
-          if (iter_out) {                                           // wave-uniform
-            const double r4 = sqrt(kf[0]), r5 = sqrt(kf[1]), r6 = sqrt(kf[2]), r7 = sqrt(kf[3]);
-            if (lane == 0) {
-              double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
-              rec[4] = r4; rec[5] = r5; rec[6] = r6; rec[7] = r7;
-              rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
-              rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
-            }
-          }
           double kmax2 = kf[0];                                     // KKTError::Max() squared
           kmax2 = kf[1] > kmax2 ? kf[1] : kmax2; kmax2 = kf[2] > kmax2 ? kf[2] : kmax2; kmax2 = kf[3] > kmax2 ? kf[3] : kmax2;
           if (kmax2 < sp.termination_kkt_tol * sp.termination_kkt_tol && cur_mu < sp.termination_complementarity_tol) {  // qp.cc:132-137
             term = MO_SATISFIED_KKT_TOL;
-            break;
-          }
-          if (kmax2 <= mu * mu || !sp.decrease_mu_only_on_small_error) {                       // qp.cc:140-146 (mu > 0)
+            stop = true;
+          } else if (kmax2 <= mu * mu || !sp.decrease_mu_only_on_small_error) {               // qp.cc:140-146 (mu > 0)
             if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= sp.sigma;
             else mu = sp.sigma * cur_mu;
           }
         }
-        if (it >= sp.max_iterations) break;                          // MAX_ITERATIONS, qp.cc:149
-        if (iter_out) {                                              // kkt_prev is only ever recorded, qp.cc:118
-          double ki[4];
-          kkt_errors_sq(mu, ki);
-          const double r0 = sqrt(ki[0]), r1 = sqrt(ki[1]), r2 = sqrt(ki[2]), r3 = sqrt(ki[3]);
-          if (lane == 0) {
-            double* rec = iter_out + (size_t)it * MO_ITER_RECORD;
-            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
+        if (it >= sp.max_iterations) stop = true;                    // MAX_ITERATIONS, qp.cc:149
+        if (iter_out) {                                              // wave-uniform
+          // The records want NORMS: kkt_after of the previous iteration (lanes 0-3) and kkt_prev of this one (lanes 4-7, qp.cc:118) take
+          // ONE lane-parallel f64 square root (~25 VALU instructions) instead of eight wave-wide ones.
+          double ki[4] = {0.0, 0.0, 0.0, 0.0};
+          if (!stop) kkt_errors_sq(mu, ki);
+          double sq = kf[0];
+          sq = lane == 1 ? kf[1] : sq; sq = lane == 2 ? kf[2] : sq; sq = lane == 3 ? kf[3] : sq;
+          sq = lane == 4 ? ki[0] : sq; sq = lane == 5 ? ki[1] : sq; sq = lane == 6 ? ki[2] : sq; sq = lane == 7 ? ki[3] : sq;
+          const double rt = sqrt(sq);
+          if (have_prev && lane < 4) iter_out[(size_t)(it - 1) * MO_ITER_RECORD + 4 + lane] = rt;
+          if (!stop && lane >= 4 && lane < 8) iter_out[(size_t)it * MO_ITER_RECORD + (lane - 4)] = rt;
+          if (have_prev && lane == 0) {
+            double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
+            rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
+            rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
           }
         }
+        if (stop) break;
       }
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
       const bool predictor_pass = use_pc && !guess_pass;  // Mehrotra: solve with mu = 0, probe, then the corrector through the same factors
