@@ -479,7 +479,11 @@ template <int NT> struct SolveCfg32 {
   static constexpr int SLOT = NH * 1024 + 64;
   static constexpr int D = 4;
   static constexpr int VEC = (6 * N + 32) * 4;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32]
-  static constexpr int LDS = D * SLOT + VEC;
+  // Tile park (as in the fp64 Solve kernel): after the first pass has streamed J the ring is idle, and in fp32 ALL G tiles (1 KiB each,
+  // lane-linear) + c fit the wave's share of the LDS (n = 128: 36.5 KiB of 40 at one wave per SIMD; n = 64: 10.3 KiB of 13.6 at three)
+  static constexpr int NTILES = NT * (NT + 1) / 2;
+  static constexpr int AREA = D * SLOT > NTILES * 1024 + N * 4 ? D * SLOT : NTILES * 1024 + N * 4;
+  static constexpr int LDS = AREA + VEC;
 };
 
 __device__ inline float wave_sum_f32(float v) { return cross_row_sum_f32(row_sum_f32(v)); }
@@ -549,7 +553,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
   __shared__ __attribute__((aligned(16))) char smem_all[WAVES * C::LDS];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   char* const smem = smem_all + wave * C::LDS;
-  float* const xs = reinterpret_cast<float*>(smem + D * SLOT);  // x, natural order
+  static_assert(WAVES * C::LDS <= 160 * 1024, "LDS budget");
+  float* const xs = reinterpret_cast<float*>(smem + C::AREA);   // x, natural order
   float* const xp = xs + N;                                      // x, position order
   float* const azS = xp + N;                                     // sum a z per variable, natural order
   float* const diagS = azS + N;                                  // barrier diagonal per variable
@@ -674,10 +679,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     };
     // G = J^T J + lambda I and c = J^T r do not change between the passes: the first pass parks its tiles in a per-problem scratch
     // (plan-owned, a.G_out; lane-linear), later passes reload them instead of re-streaming J
-    constexpr int NTILES = NT * (NT + 1) / 2, TILE_SCRATCH = NTILES * 256 + NT * 64;
-    // (indexed by the wave's slot in the persistent grid, not by problem: 2 048 slots x 38 KB stay in the last-level cache)
-    float* const Gt = (!qpl && a.G_out) ? (float*)a.G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)a.G_out_stride : nullptr;
-    static_assert(TILE_SCRATCH <= (NT * (NT + 1) / 2) * 256 + NT * 64, "mo_api.hip sizes a slot with this formula");
+    constexpr int NTILES = C::NTILES;
+    float* const park = reinterpret_cast<float*>(smem);            // NTILES tiles (256 floats each, lane-linear), then c (V16, N floats)
+    float* const cpark = park + NTILES * 256;
     bool tiles_cached = false;
     float mu_used = mu;
     float ip_alpha_p = 1.0f, ip_alpha_d = 1.0f;
@@ -775,26 +779,28 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
           for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == 4 * g + t) ? lam : 0.0f;
           cvec[c] = cross_row_sum_f32(cpart[c]);
         }
-        if (Gt) {  // park the tiles and c for the following passes
+        if (!iterate_mode) {  // park the tiles and c in the (now idle) ring for the following passes
           int ti = 0;
 #pragma unroll
           for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
-            for (int tb = ta; tb < NT; ++tb, ++ti) *(f4*)(Gt + ((size_t)ti * 64 + lane) * 4) = U[ta * NB + tb];
+            for (int tb = ta; tb < NT; ++tb, ++ti) *(f4*)(park + (ti * 64 + lane) * 4) = U[ta * NB + tb];
           }
+          if (g == 0) {
 #pragma unroll
-          for (int c = 0; c < NT; ++c) Gt[NTILES * 256 + c * 64 + lane] = cvec[c];
+            for (int c = 0; c < NT; ++c) cpark[16 * c + j] = cvec[c];
+          }
           tiles_cached = true;
         }
-      } else {  // reload what the first pass parked
+      } else {  // fetch what the first pass parked
         int ti = 0;
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
-          for (int tb = ta; tb < NT; ++tb, ++ti) U[ta * NB + tb] = *(const f4*)(Gt + ((size_t)ti * 64 + lane) * 4);
+          for (int tb = ta; tb < NT; ++tb, ++ti) U[ta * NB + tb] = *(const f4*)(park + (ti * 64 + lane) * 4);
         }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) cvec[c] = Gt[NTILES * 256 + c * 64 + lane];
+        for (int c = 0; c < NT; ++c) cvec[c] = cpark[16 * c + j];
       }
 #pragma unroll
       for (int c = 0; c < NT; ++c) {  // [A_eq^T] tile column

@@ -489,7 +489,7 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
     a.G_out = plan->G_scratch; a.G_out_stride = (long long)(n * n); a.G_out_ld = (int)n;
     a.c_out = plan->c_scratch; a.c_out_stride = (long long)n;
   }
-  if (use_fused) {
+  if (use_fused && plan->desc.dtype == MO_F64 && plan->desc.n > 32) {   // (fp32 and the 32 grid park every tile in LDS)
     // Tile park of the fused Solve kernels: the G tiles a wave cannot keep in LDS between the passes go to a scratch indexed by the
     // wave's slot in the persistent grid (one workgroup per CU, at most twelve waves each), so its size does not depend on the batch
     // and the lines a wave re-reads every pass stay in its XCD's L2.  Optional: without it the kernel rebuilds the tiles every pass.

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Copy gpurun_out/prof_<tag>/{summary.json, kernel_stats.csv} of every round-2 tag into profiles/ and print one line per kernel
+"""Copy gpurun_out/prof_<tag>/{summary.json, kernel_stats.csv} of every tag of the round (default r03) into profiles/ and print one line per kernel
 (average launch, units/s, instruction mix per problem, HBM bytes) -- the numbers profiles/README.md quotes."""
 import glob
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_r02_*"))):
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{ROUND}_*"))):
     tag = os.path.basename(d)[5:]
     if not os.path.exists(os.path.join(d, "summary.json")):
         continue
