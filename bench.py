@@ -55,8 +55,8 @@ def measured_traffic(kernel_name: str, config: str, batch: int):
     src = {"source": None}
     if not kernel_name.startswith("fused"):
         return None, src
-    want = {"cfg3": "r02_step_cfg3_pmc_summary.json", "cfg5": "r02_step_cfg5shard_pmc_summary.json",
-            "cfg2": "r02_step_cfg2_pmc_summary.json"}.get(config)
+    want = {"cfg3": "r03_step_cfg3_pmc_summary.json", "cfg5": "r03_step_cfg5shard_pmc_summary.json",
+            "cfg2": "r03_step_cfg2_pmc_summary.json"}.get(config)
     if want is None:
         return None, src
     path = os.path.join(ROOT, "profiles", want)

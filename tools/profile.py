@@ -91,6 +91,9 @@ def main():
                         summary[k]["counter_pass_kernel_ns"] = ns
                         summary[k]["effective_clock_ghz"] = summary[k]["GRBM_GUI_ACTIVE"] / 8.0 / ns
     json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    if "--keep-raw" not in opts:   # the raw per-dispatch tables are 20-40 MB per tag; gpurun merges at most 64 MiB back
+        for name in ["stats"] + [f"pmc{i}" for i in range(1, len(PMC_GROUPS) + 1)]:
+            subprocess.run(["rm", "-rf", os.path.join(out, name)])
     for k, v in summary.items():
         if k != "_meta":
             print(k, json.dumps({c: v[c] for c in ("kernel_stats", "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "effective_clock_ghz") if c in v}))
