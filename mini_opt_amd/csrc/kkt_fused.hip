@@ -1515,10 +1515,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   double* const ysm = tmp + N;                                    // [0, YN): y ; [YN, 2 YN): -r_pe
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
-  const int k = a.k, m = a.m, m_r = a.m_r;
-  const int nn = a.n;  // actual number of variables <= N (see the step kernel)
-  const double inv_m = m > 0 ? 1.0 / (double)m : 0.0;
-  const mo_solve_params& sp = a.sp;
+  const double inv_m = a.m > 0 ? 1.0 / (double)a.m : 0.0;   // (k, m, n, m_r are read per problem / per pass, see below)
   for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
   lds_fence();
 
@@ -1541,6 +1538,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
+    // The argument block is re-read from the kernarg segment where it is used (scalar loads, K$ hits): held in SGPRs for the whole kernel it
+    // overflows the SGPR file -- round 2's build parked ~270 SGPRs in VGPR lanes and executed hundreds of v_readlane / v_writelane VALU
+    // instructions per pass to get at them (the step kernel has had this since round 1).
+    KArgs ka = fresh_args();
+    // (the shape, too: conditions on k / m / n would otherwise be evaluated once per kernel and their lane masks kept in SGPR pairs throughout)
+    const int k = ka->k, m = ka->m, nn = ka->n;   // actual number of variables nn <= N (see the step kernel)
     const bool last_of_chunk = p + 1 >= chunk_end;
     int next_chunk = 0;
     unsigned long long next_ticket = 0;
@@ -1548,17 +1551,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       next_chunk = chunk_for(p);
       next_ticket = take_ticket(next_chunk);
     }
-    if (a.skip && a.skip[p * a.skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
+    if (ka->skip && ka->skip[p * ka->skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
       if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
       continue;
     }
     const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
 
-    const double* Jp = QPL ? nullptr : (const double*)a.J + p * a.J_stride;
-    const double* rg = QPL ? nullptr : (const double*)a.r + p * a.r_stride;
-    double* vp = (double*)a.vars + p * a.vars_stride;
-    const double lam_in = a.lambda_vec ? ((const double*)a.lambda_vec)[p * a.lambda_vec_stride] : a.lambda;
+    const double* Jp = QPL ? nullptr : (const double*)ka->J + p * ka->J_stride;
+    const double* rg = QPL ? nullptr : (const double*)ka->r + p * ka->r_stride;
+    double* vp = (double*)ka->vars + p * ka->vars_stride;
+    const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
     const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // a given G already carries the LM damping
 
     // ---- constants of the problem
@@ -1568,15 +1571,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       const int ix = lane + 64 * ci;
       cvar[ci] = 0; ca[ci] = 1.0; cb[ci] = 0.0;
       if (ix < m) {
-        cvar[ci] = a.cons_var[p * a.cons_stride + ix];
-        ca[ci] = ((const double*)a.cons_a)[p * a.cons_stride + ix];
-        cb[ci] = ((const double*)a.cons_b)[p * a.cons_stride + ix];
+        cvar[ci] = ka->cons_var[p * ka->cons_stride + ix];
+        ca[ci] = ((const double*)ka->cons_a)[p * ka->cons_stride + ix];
+        cb[ci] = ((const double*)ka->cons_b)[p * ka->cons_stride + ix];
       }
     }
     double b_col[NY];
 #pragma unroll
-    for (int q = 0; q < NY; ++q) b_col[q] = (16 * q + j < k) ? ((const double*)a.b + p * a.b_stride)[16 * q + j] : 0.0;
-    const double* const Ap = k > 0 ? (const double*)a.A + p * a.A_stride : nullptr;
+    for (int q = 0; q < NY; ++q) b_col[q] = (16 * q + j < k) ? ((const double*)ka->b + p * ka->b_stride)[16 * q + j] : 0.0;
+    const double* const Ap = k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr;
 
     // ---- state: x in the permuted V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
     double xv[NT], yv[NY], cs[MC], cz[MC];  // yv[q]: equality row 16 q + j
@@ -1587,9 +1590,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
     for (int ci = 0; ci < MC; ++ci) { cs[ci] = 1.0; cz[ci] = 1.0; }
     // MODE_RESIDUAL: EvaluateKKTConditions + ComputeErrors (qp.cc:391-437) on the caller's state -- part A of a pass, then the outputs
-    const bool residual_mode = a.mode == MODE_RESIDUAL;
-    const bool iterate_mode = a.mode == MODE_ITERATE || residual_mode;  // one Iterate (qp.cc:153-201) on the caller's state and mu
-    if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+    const bool residual_mode = ka->mode == MODE_RESIDUAL;
+    const bool iterate_mode = ka->mode == MODE_ITERATE || residual_mode;  // one Iterate (qp.cc:153-201) on the caller's state and mu
+    if (iterate_mode || ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
       ldv_n<NT, QPL>(vp, j, nn, xv);
 #pragma unroll
       for (int q = 0; q < NY; ++q)
@@ -1609,9 +1612,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
     int term = MO_MAX_ITERATIONS, it = 0;
-    double mu = iterate_mode ? (a.mu ? ((const double*)a.mu)[p * a.mu_stride] : 0.0) : sp.initial_mu;
-    bool guess_pass = !iterate_mode && sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
-    double* iter_out = a.iterations ? (double*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
+    double mu = iterate_mode ? (ka->mu ? ((const double*)ka->mu)[p * ka->mu_stride] : 0.0) : ka->sp.initial_mu;
+    bool guess_pass = !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
+    double* iter_out = ka->iterations ? (double*)ka->iterations + (size_t)p * ka->sp.max_iterations * MO_ITER_RECORD : nullptr;
 
     // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
     auto clamp_and_init_slacks = [&]() {
@@ -1641,13 +1644,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           sz += cs[ci] * cz[ci];
         }
       }
-      if (sp.initialize_mu_with_complementarity) {  // qp.cc:115
+      if (ka->sp.initialize_mu_with_complementarity) {  // qp.cc:115
         const double t = wave_sum_f64(sz);
         mu = t * inv_m;
       }
     };
-    if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
-    if (!iterate_mode && sp.initial_guess_method == MO_GUESS_USER_PROVIDED && sp.initialize_mu_with_complementarity) {
+    if (st == MO_STATUS_OK && !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+    if (!iterate_mode && ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED && ka->sp.initialize_mu_with_complementarity) {
       double sz = 0.0;  // qp.cc:115 on the caller's state: mu = s^T z / M (0 without inequalities, qp.cc:509-516)
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci)
@@ -1668,13 +1671,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       } else { o[1] = 0.0; o[3] = 0.0; }
     };
     // G = J^T J + lambda I and c = J^T r do not change between the passes of one Solve: the first pass parks its tiles in a per-problem
-    // scratch (plan-owned, a.G_out; lane-linear, every lane reads back exactly what it wrote), later passes reload 22 KB instead of
+    // scratch (plan-owned, ka->G_out; lane-linear, every lane reads back exactly what it wrote), later passes reload 22 KB instead of
     // re-streaming 64 KB of J and redoing 320 of the 440 MFMAs (n = 64 figures).
     constexpr int PARK_LDS = C::PARK_LDS, PARK_GLOBAL = C::PARK_GLOBAL;
     double* const park = reinterpret_cast<double*>(smem);             // PARK_LDS tiles (256 doubles each, lane-linear), then c (V16, N doubles)
     double* const cpark = park + PARK_LDS * 256;
     // the tiles that do not fit: global scratch of this wave's slot in the persistent grid (plan-owned; NULL: re-stream / re-load every pass)
-    double* const Gt = (PARK_GLOBAL > 0 && a.G_out) ? (double*)a.G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)a.G_out_stride : nullptr;
+    double* const Gt = (PARK_GLOBAL > 0 && ka->G_out) ? (double*)ka->G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)ka->G_out_stride : nullptr;
     const bool can_park = PARK_GLOBAL == 0 || Gt != nullptr;
     bool tiles_cached = false;
     // Lanes whose J piece lies beyond the row never receive DMA data and must read zeros from the ring: a problem that parked tiles there
@@ -1687,26 +1690,28 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
     // Mehrotra predictor-corrector (qp.cc:170-187): solve with mu = 0, probe alpha(tau = 1), then solve again with the second-order
     // term ds_aff dz_aff and mu = sigma mu_input on the right-hand side -- through the factors of the first solve (solve_second_rhs).
-    const bool use_pc = (iterate_mode ? a.barrier_strategy : sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
+    const bool use_pc = (iterate_mode ? ka->barrier_strategy : ka->sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
     double ip_mu = mu, probe_p = __builtin_nan(""), probe_d = __builtin_nan(""), mu_aff = __builtin_nan(""), mu_pc = 0.0;
 
     while (st == MO_STATUS_OK) {
-      const bool include_ineq = !guess_pass && !(residual_mode && (a.flags & MO_STEP_NO_INEQUALITIES));
+      const bool include_ineq = !guess_pass && !(residual_mode && (ka->flags & MO_STEP_NO_INEQUALITIES));
       // lane coordinates are re-made opaque every pass: nothing derived from them may be hoisted out of the pass loop and
       // kept in VGPRs across the factorisation (see the step kernel)
       const int lane = lane_id(), g = lane >> 4, j = lane & 15;  // shadow the per-problem copies inside the pass
+      ka = fresh_args();
+      const int k = ka->k, m = ka->m, nn = ka->n, m_r = ka->m_r;
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       JStream<NT, D, JMODE, NY> stream;
       const bool build_now = __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;          // wave-uniform, and hipcc must know it
       const bool stream_now = !QPL && build_now;
       if (stream_now) {
-        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, a.J_row_major ? (long long)a.J_ld : 1ll, a.J_row_major ? 1ll : (long long)a.J_ld);
+        stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, ka->J_row_major ? (long long)ka->J_ld : 1ll, ka->J_row_major ? 1ll : (long long)ka->J_ld);
         stream.prologue();
       }
       d4 U[NB * NB];
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-      load_a_tiles<NT, QPL, NY>(Ap, a.A_ld, k, nn, g, j, U);
+      load_a_tiles<NT, QPL, NY>(Ap, ka->A_ld, k, nn, g, j, U);
       // publish the state for the layout conversions below; zero the per-variable scatter arrays
       if (g == 0) {
         stv<NT, QPL>(xs, j, xv);
@@ -1722,7 +1727,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       double cvec[NT];
       if (QPL && build_now) {
-        load_g_tiles<NT, NY>((const double*)a.G + p * a.G_stride, a.G_ld, (const double*)a.c + p * a.c_stride, nn, g, j, U, cvec);
+        load_g_tiles<NT, NY>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, nn, g, j, U, cvec);
       } else if (stream_now) {
         double cpart[NT];
 #pragma unroll
@@ -1841,7 +1846,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       }
       }
       if (residual_mode) {  // r_ = [r_d | r_comp | r_pe | r_pi] (qp.cc:391-420) and the four norms of ComputeErrors (qp.cc:423-437)
-        double* ro = (double*)a.r_out + p * a.r_out_stride;
+        double* ro = (double*)ka->r_out + p * ka->r_out_stride;
         if (g == 0) {
           stv_n<NT, QPL>(ro, j, nn, r_d);
 #pragma unroll
@@ -1851,12 +1856,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
         for (int ci = 0; ci < MC; ++ci)
           if (lane + 64 * ci < m) { ro[nn + lane + 64 * ci] = r_comp[ci]; ro[nn + m + k + lane + 64 * ci] = r_pi[ci]; }
-        if (a.kkt_out) {
+        if (ka->kkt_out) {
           double kq[4];
           kkt_errors_sq(mu, kq);
           if (!include_ineq) { kq[1] = 0.0; kq[3] = 0.0; }
           const double e0 = sqrt(kq[0]), e1 = sqrt(kq[1]), e2 = sqrt(kq[2]), e3 = sqrt(kq[3]);
-          if (lane == 0) { double* ko = (double*)a.kkt_out + 4 * p; ko[0] = e0; ko[1] = e1; ko[2] = e2; ko[3] = e3; }
+          if (lane == 0) { double* ko = (double*)ka->kkt_out + 4 * p; ko[0] = e0; ko[1] = e1; ko[2] = e2; ko[3] = e3; }
         }
         break;
       }
@@ -1870,15 +1875,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           const double cur_mu = n_rc1 * inv_m;                      // ComputeMu, qp.cc:509-516 (one f64 division per kernel, not per pass)
           double kmax2 = kf[0];                                     // KKTError::Max() squared
           kmax2 = kf[1] > kmax2 ? kf[1] : kmax2; kmax2 = kf[2] > kmax2 ? kf[2] : kmax2; kmax2 = kf[3] > kmax2 ? kf[3] : kmax2;
-          if (kmax2 < sp.termination_kkt_tol * sp.termination_kkt_tol && cur_mu < sp.termination_complementarity_tol) {  // qp.cc:132-137
+          if (kmax2 < ka->sp.termination_kkt_tol * ka->sp.termination_kkt_tol && cur_mu < ka->sp.termination_complementarity_tol) {  // qp.cc:132-137
             term = MO_SATISFIED_KKT_TOL;
             stop = true;
-          } else if (kmax2 <= mu * mu || !sp.decrease_mu_only_on_small_error) {               // qp.cc:140-146 (mu > 0)
-            if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= sp.sigma;
-            else mu = sp.sigma * cur_mu;
+          } else if (kmax2 <= mu * mu || !ka->sp.decrease_mu_only_on_small_error) {               // qp.cc:140-146 (mu > 0)
+            if (ka->sp.barrier_strategy == MO_FIXED_DECREASE) mu *= ka->sp.sigma;
+            else mu = ka->sp.sigma * cur_mu;
           }
         }
-        if (it >= sp.max_iterations) stop = true;                    // MAX_ITERATIONS, qp.cc:149
+        if (it >= ka->sp.max_iterations) stop = true;                    // MAX_ITERATIONS, qp.cc:149
         if (iter_out) {                                              // wave-uniform
           // The records want NORMS: kkt_after of the previous iteration (lanes 0-3) and kkt_prev of this one (lanes 4-7, qp.cc:118) take
           // ONE lane-parallel f64 square root (~25 VALU instructions) instead of eight wave-wide ones.
@@ -1899,6 +1904,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         if (stop) break;
       }
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
+      ka = fresh_args();
       const bool predictor_pass = use_pc && !guess_pass;  // Mehrotra: solve with mu = 0, probe, then the corrector through the same factors
       const double mu_step = m > 0 ? (predictor_pass ? 0.0 : mu) : 0.0;  // qp.cc:165-187
       double aff[MC], cs_inv[MC];
@@ -2069,8 +2075,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
       ++it;
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
-        if (a.delta) {
-          double* dp = (double*)a.delta + p * a.delta_stride;
+        if (ka->delta) {
+          double* dp = (double*)ka->delta + p * ka->delta_stride;
           for (int i = lane; i < nn; i += 64) dp[i] = tmp[i];  // dx, natural order
 #pragma unroll
           for (int ci = 0; ci < MC; ++ci)
@@ -2079,8 +2085,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           for (int q = 0; q < NY; ++q)
             if (g == 0 && 16 * q + j < k) dp[nn + m + 16 * q + j] = dyv[q];
         }
-        if (a.ip_out && lane == 0) {
-          double* ip = (double*)a.ip_out + p * MO_IP_RECORD;
+        if (ka->ip_out && lane == 0) {
+          double* ip = (double*)ka->ip_out + p * MO_IP_RECORD;
           ip[0] = ip_mu; ip[1] = ap; ip[2] = ad;  // outputs.mu = mu_input (sigma mu_input after a corrector), qp.cc:160, 183
           ip[3] = probe_p; ip[4] = probe_d; ip[5] = mu_aff;
         }
@@ -2089,6 +2095,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     }
 
     // ---- outputs: state, termination, iteration count, Lagrange summary, status
+    ka = fresh_args();
     if (!residual_mode) {  // the state is an input only there
       if (g == 0) {
         stv_n<NT, QPL>(vp, j, nn, xv);
@@ -2108,12 +2115,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     }
     const double ymin = row_min(ymin_l), yabs = -row_min(yabs_l);
     if (lane == 0) {
-      if (a.termination) a.termination[p] = term;
-      if (a.num_iterations) a.num_iterations[p] = it;
-      if (a.status) a.status[p] = st;
-      if (a.lagrange) {  // qp.cc:539-546
-        ((double*)a.lagrange)[2 * p] = k > 0 ? ymin : __builtin_nan("");
-        ((double*)a.lagrange)[2 * p + 1] = k > 0 ? yabs : __builtin_nan("");
+      if (ka->termination) ka->termination[p] = term;
+      if (ka->num_iterations) ka->num_iterations[p] = it;
+      if (ka->status) ka->status[p] = st;
+      if (ka->lagrange) {  // qp.cc:539-546
+        ((double*)ka->lagrange)[2 * p] = k > 0 ? ymin : __builtin_nan("");
+        ((double*)ka->lagrange)[2 * p + 1] = k > 0 ? yabs : __builtin_nan("");
       }
     }
     lds_fence();

@@ -1,8 +1,14 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-export MO_GIT_HEAD=$(cat gpurun_out/.head 2>/dev/null)
-timeout -k 10 900 bash tools/profile_all.sh > gpurun_out/r3_profile_all.log 2>&1 || { tail -20 gpurun_out/r3_profile_all.log; exit 1; }
-python3 tools/collect_profiles.py r03 | tee gpurun_out/r3_profile_table.txt
-du -sh gpurun_out
-python bench.py > gpurun_out/r3_bench_b.json 2> gpurun_out/r3_bench_b.err; tail -c 300 gpurun_out/r3_bench_b.json
+timeout -k 10 700 python -m pytest tests -m gpu -q -p no:cacheprovider -x > gpurun_out/r3_tests_h.log 2>&1
+rc=$?; echo "all tests rc=$rc"; tail -4 gpurun_out/r3_tests_h.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+one() { python tools/bench_kernels.py "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4g M/s  %.4f ms' % (d['units_per_s']/1e6, d['ms_mean']))"; }
+for rep in 1 2 3; do
+  echo -n "solve    "; one --mode solve --config cfg3
+  echo -n "solve_pc "; one --mode solve_pc --config cfg3
+  echo -n "step     "; one --mode step --config cfg3
+done
+echo -n "solve cfg2 "; one --mode solve --config cfg2 --batch 65536
+echo -n "solve k24 "; one --mode solve --shape 64,24,32,128
