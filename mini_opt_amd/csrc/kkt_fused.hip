@@ -2,7 +2,8 @@
 //
 // One 64-lane wavefront owns one QP at a time and keeps the WHOLE reduced KKT matrix in registers as 16x16 tiles in the
 // v_mfma_f64_16x16x4_f64 C/D fragment layout (lane (g = l>>4, j = l&15), register t holds element (row g + 4t, column j)).
-// Shapes: any n <= 128 (padded inside the kernel to a 32 / 64 / 96 / 128 tile grid), k <= 15, m <= 128; see fused_supported().
+// Shapes: any n <= 128 (padded inside the kernel to a 32 / 64 / 96 / 128 tile grid), k <= 31 (16 .. 31: a second y tile, kkt_fused_ny2.hip),
+// m <= 256 (one, two or four constraint slots per lane; four: kkt_fused_mc4.hip); see fused_supported().
 //
 //   P0  The small per-problem vectors (x, s, z, y, b_eq, constraints) go global -> LDS by dword DMA, behind the ring fill.
 //   P1  J (m_r x n, row-major) is streamed from HBM exactly once through a per-wave LDS-DMA ring straight into MFMA operand
