@@ -2202,7 +2202,9 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
   static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
-  const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);  // measured best: 3 (A/B in DESIGN.md)
+  // measured best: 3 (A/B in DESIGN.md; round 3: a fourth wave per SIMD on the 32 grid for batches of 3 072 < B <= 4 096 -- one round instead of
+  // two for a third of the waves -- is 10 % SLOWER at BASELINE configs[1]: 0.136 vs 0.123 ms)
+  const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);
   const int sw = (env_sw >= 0 && env_sw <= 6) ? env_sw : 3;
   long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
   const long long blocks_needed = (a.batch + 4 * wps - 1) / (4 * wps);
