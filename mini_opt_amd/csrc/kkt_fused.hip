@@ -1043,8 +1043,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     const int slot = wave >> 2;
     for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
+  // The FIRST chunk of every wave is static (wave w of the persistent grid takes problems [w c0, (w + 1) c0)); tickets from the counter start
+  // behind that part.  All waves asking one counter word for their first ticket at kernel start costs 3 072 / 88 M atomics/s = 35 us: most
+  // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
-  long long p = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     if (a.chain_prio) __builtin_amdgcn_s_setprio(0);
     MO_STAMP(6);
     if (last_of_chunk) {
-      p = uniform64(next_ticket);
+      p = uniform64(next_ticket) + ticket_base;
       chunk_end = p + next_chunk;
     } else {
       ++p;
@@ -1358,8 +1362,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  // The FIRST chunk of every wave is static (wave w of the persistent grid takes problems [w c0, (w + 1) c0)); tickets from the counter start
+  // behind that part.  All waves asking one counter word for their first ticket at kernel start costs 3 072 / 88 M atomics/s = 35 us: most
+  // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
-  long long p = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
   while (p < a.batch) {
     const bool last_of_chunk = p + 1 >= chunk_end;
@@ -1459,7 +1467,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
     }
     if (g == 0) stv_n<NT, false>((double*)a.c_out + p * a.c_out_stride, j, nn, cvec);
     if (lane == 0 && a.half_sq_out) ((double*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = half_sq;
-    if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+    if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
   }
 }
 
@@ -1534,8 +1542,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  // The FIRST chunk of every wave is static (wave w of the persistent grid takes problems [w c0, (w + 1) c0)); tickets from the counter start
+  // behind that part.  All waves asking one counter word for their first ticket at kernel start costs 3 072 / 88 M atomics/s = 35 us: most
+  // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
-  long long p = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -1553,7 +1565,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       next_ticket = take_ticket(next_chunk);
     }
     if (ka->skip && ka->skip[p * ka->skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
-      if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+      if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
       continue;
     }
     const int lane = lane_id();
@@ -2126,7 +2138,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     }
     lds_fence();
     if (last_of_chunk) {
-      p = uniform64(next_ticket);
+      p = uniform64(next_ticket) + ticket_base;
       chunk_end = p + next_chunk;
     } else {
       ++p;

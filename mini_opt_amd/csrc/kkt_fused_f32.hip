@@ -224,8 +224,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     const int slot = wave >> 2;
     for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
+  // The FIRST chunk of every wave is static (wave w of the persistent grid takes problems [w c0, (w + 1) c0)); tickets from the counter start
+  // behind that part.  All waves asking one counter word for their first ticket at kernel start costs 3 072 / 88 M atomics/s = 35 us: most
+  // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
-  long long p = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     }
     lds_fence32();  // the LDS vectors are re-initialised by the next problem
     if (last_of_chunk) {
-      p = uniform64(next_ticket);
+      p = uniform64(next_ticket) + ticket_base;
       chunk_end = p + next_chunk;
     } else {
       ++p;
@@ -583,8 +587,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  // The FIRST chunk of every wave is static (wave w of the persistent grid takes problems [w c0, (w + 1) c0)); tickets from the counter start
+  // behind that part.  All waves asking one counter word for their first ticket at kernel start costs 3 072 / 88 M atomics/s = 35 us: most
+  // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
-  long long p = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       next_ticket = take_ticket(next_chunk);
     }
     if (a.skip && a.skip[p * a.skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
-      if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+      if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
       continue;
     }
     const int lane = lane_id32();
@@ -1100,7 +1108,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     wait_vmcnt32<0>();  // nothing of this problem's ring traffic is left in flight (a pass may leave through a break)
     lds_fence32();
     if (last_of_chunk) {
-      p = uniform64(next_ticket);
+      p = uniform64(next_ticket) + ticket_base;
       chunk_end = p + next_chunk;
     } else {
       ++p;
@@ -1136,8 +1144,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  // The FIRST chunk of every wave is static (wave w of the persistent grid takes problems [w c0, (w + 1) c0)); tickets from the counter start
+  // behind that part.  All waves asking one counter word for their first ticket at kernel start costs 3 072 / 88 M atomics/s = 35 us: most
+  // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
-  long long p = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
   while (p < a.batch) {
     const bool last_of_chunk = p + 1 >= chunk_end;
@@ -1279,7 +1291,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
     }
     if (lane == 0 && a.half_sq_out) ((float*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = half_sq;
     lds_fence32();
-    if (last_of_chunk) { p = uniform64(next_ticket); chunk_end = p + next_chunk; } else { ++p; }
+    if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
   }
 }
 

@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_tiny_kernel(const KernelAr
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  // the first ticket of every wave is static (see kkt_fused.hip): tickets from the counter start behind that part
   int chunk = chunk_for(0);
-  long long base = uniform64(take_ticket(chunk));
+  const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
+  long long base = ((long long)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * chunk;
 
   while (base < batch) {
     const int len = (batch - base < chunk) ? (int)(batch - base) : chunk;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_tiny_kernel(const KernelAr
     }
     lds_fence();
   }  // problems of this ticket
-    base = uniform64(next_ticket);
+    base = uniform64(next_ticket) + ticket_base;
     chunk = next_chunk;
   }
 }
