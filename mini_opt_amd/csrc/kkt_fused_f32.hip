@@ -567,10 +567,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
   float* const ysm = tmp + N;                                    // [0,16): y ; [16,32): -r_pe
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
-  const int k = a.k, m = a.m, m_r = a.m_r;
+  const int m = a.m, m_r = a.m_r;
   const int nsteps = m_r >> 2;
   const float inv_m = m > 0 ? 1.0f / (float)m : 0.0f;
-  const mo_solve_params& sp = a.sp;
   const bool qpl = a.J == nullptr;  // wave-uniform: QP-level input (G, c given)
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
@@ -596,6 +595,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
+    // the argument block and the shape are re-read from the kernarg segment where they are used (see kkt_fused_solve_kernel): held in SGPRs
+    // for the whole kernel they were spilled into VGPR lanes (226 v_writelane / 534 v_readlane in round 2's build)
+    KArgs32 ka = fresh_args32();
+    const int k = ka->k, m = ka->m;
     const bool last_of_chunk = p + 1 >= chunk_end;
     int next_chunk = 0;
     unsigned long long next_ticket = 0;
@@ -603,35 +606,35 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       next_chunk = chunk_for(p);
       next_ticket = take_ticket(next_chunk);
     }
-    if (a.skip && a.skip[p * a.skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
+    if (ka->skip && ka->skip[p * ka->skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
       if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
       continue;
     }
     const int lane = lane_id32();
     const int g = lane >> 4, j = lane & 15;
 
-    float* vp = (float*)a.vars + p * a.vars_stride;
-    const float lam_in = a.lambda_vec ? ((const float*)a.lambda_vec)[p * a.lambda_vec_stride] : (float)a.lambda;
+    float* vp = (float*)ka->vars + p * ka->vars_stride;
+    const float lam_in = ka->lambda_vec ? ((const float*)ka->lambda_vec)[p * ka->lambda_vec_stride] : (float)ka->lambda;
     const float lam = (!qpl && lam_in > 0.0f) ? lam_in : 0.0f;  // a given G already carries the LM damping
 
     // ---- constants of the problem
     int cvar = 0; float ca = 1.0f, cb = 0.0f;
     if (lane < m) {
-      cvar = a.cons_var[p * a.cons_stride + lane];
-      ca = ((const float*)a.cons_a)[p * a.cons_stride + lane];
-      cb = ((const float*)a.cons_b)[p * a.cons_stride + lane];
+      cvar = ka->cons_var[p * ka->cons_stride + lane];
+      ca = ((const float*)ka->cons_a)[p * ka->cons_stride + lane];
+      cb = ((const float*)ka->cons_b)[p * ka->cons_stride + lane];
     }
     float b_col = 0.0f;
-    if (j < k) b_col = ((const float*)a.b + p * a.b_stride)[j];
-    const float* const Ap = k > 0 ? (const float*)a.A + p * a.A_stride : nullptr;
+    if (j < k) b_col = ((const float*)ka->b + p * ka->b_stride)[j];
+    const float* const Ap = k > 0 ? (const float*)ka->A + p * ka->A_stride : nullptr;
 
     // ---- state: x in the V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
     float xv[NT], yv = 0.0f, cs = 1.0f, cz = 1.0f;
 #pragma unroll
     for (int c = 0; c < NT; ++c) xv[c] = 0.0f;
-    const bool residual_mode = a.mode == MODE_RESIDUAL;
-    const bool iterate_mode = a.mode == MODE_ITERATE || residual_mode;
-    if (iterate_mode || sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+    const bool residual_mode = ka->mode == MODE_RESIDUAL;
+    const bool iterate_mode = ka->mode == MODE_ITERATE || residual_mode;
+    if (iterate_mode || ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
 #pragma unroll
       for (int c = 0; c < NT; ++c) xv[c] = vp[natvar32(c, j)];
       if (j < k) yv = vp[N + m + j];
@@ -642,9 +645,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
     int term = MO_MAX_ITERATIONS, it = 0;
-    float mu = iterate_mode ? (a.mu ? ((const float*)a.mu)[p * a.mu_stride] : 0.0f) : (float)sp.initial_mu;
-    bool guess_pass = !iterate_mode && sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
-    float* iter_out = a.iterations ? (float*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
+    float mu = iterate_mode ? (ka->mu ? ((const float*)ka->mu)[p * ka->mu_stride] : 0.0f) : (float)ka->sp.initial_mu;
+    bool guess_pass = !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
+    float* iter_out = ka->iterations ? (float*)ka->iterations + (size_t)p * ka->sp.max_iterations * MO_ITER_RECORD : nullptr;
 
     // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
     auto clamp_and_init_slacks = [&]() {
@@ -668,10 +671,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
         cz = 1.0f / cs;
         sz = cs * cz;
       }
-      if (sp.initialize_mu_with_complementarity) mu = wave_sum_f32(sz) * inv_m;  // qp.cc:115
+      if (ka->sp.initialize_mu_with_complementarity) mu = wave_sum_f32(sz) * inv_m;  // qp.cc:115
     };
-    if (st == MO_STATUS_OK && !iterate_mode && sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
-    if (!iterate_mode && sp.initial_guess_method == MO_GUESS_USER_PROVIDED && sp.initialize_mu_with_complementarity)
+    if (st == MO_STATUS_OK && !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+    if (!iterate_mode && ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED && ka->sp.initialize_mu_with_complementarity)
       mu = wave_sum_f32(lane < m ? cs * cz : 0.0f) * inv_m;  // qp.cc:115 on the caller's state (0 without inequalities, qp.cc:509-516)
 
     float n_rd2 = 0, n_rpe2 = 0, n_rc2 = 0, n_rc1 = 0, n_rpi2 = 0;
@@ -686,24 +689,26 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       } else { o[1] = 0.0f; o[3] = 0.0f; }
     };
     // G = J^T J + lambda I and c = J^T r do not change between the passes: the first pass parks its tiles in a per-problem scratch
-    // (plan-owned, a.G_out; lane-linear), later passes reload them instead of re-streaming J
+    // (plan-owned, ka->G_out; lane-linear), later passes reload them instead of re-streaming J
     constexpr int NTILES = C::NTILES;
     float* const park = reinterpret_cast<float*>(smem);            // NTILES tiles (256 floats each, lane-linear), then c (V16, N floats)
     float* const cpark = park + NTILES * 256;
     bool tiles_cached = false;
     float mu_used = mu;
     float ip_alpha_p = 1.0f, ip_alpha_d = 1.0f;
-    const bool use_pc = (iterate_mode ? a.barrier_strategy : sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
+    const bool use_pc = (iterate_mode ? ka->barrier_strategy : ka->sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
     const float nanf32 = __builtin_nanf("");
     float ip_mu = mu, probe_p = nanf32, probe_d = nanf32, mu_aff = nanf32, mu_pc = 0.0f;
 
     while (st == MO_STATUS_OK) {
-      const bool include_ineq = !guess_pass && !(residual_mode && (a.flags & MO_STEP_NO_INEQUALITIES));
+      const bool include_ineq = !guess_pass && !(residual_mode && (ka->flags & MO_STEP_NO_INEQUALITIES));
       const int lane = lane_id32(), g = lane >> 4, j = lane & 15;  // re-made opaque every pass (nothing lane-derived is kept across the factorisation)
+      ka = fresh_args32();
+      const int k = ka->k, m = ka->m;
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       const bool stream_now = !qpl && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;
-      const char* jsrc = reinterpret_cast<const char*>((const float*)a.J + p * a.J_stride + (size_t)g * N + 4 * j);
-      const char* rsrc = reinterpret_cast<const char*>((const float*)a.r + p * a.r_stride);
+      const char* jsrc = reinterpret_cast<const char*>((const float*)ka->J + p * ka->J_stride + (size_t)g * N + 4 * j);
+      const char* rsrc = reinterpret_cast<const char*>((const float*)ka->r + p * ka->r_stride);
       auto issue = [&](int slot) {
         const unsigned dst = ring_base + slot * SLOT;
 #pragma unroll
@@ -729,8 +734,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       for (int i = lane; i < N; i += 64) { azS[i] = 0.0f; diagS[i] = 0.0f; rhoS[i] = 0.0f; }
       float cvec[NT];
       if (qpl) {  // only the lower triangle of G is read (qp.cc:289, 404)
-        const float* Gp = (const float*)a.G + p * a.G_stride;
-        const float* cp = (const float*)a.c + p * a.c_stride;
+        const float* Gp = (const float*)ka->G + p * ka->G_stride;
+        const float* cp = (const float*)ka->c + p * ka->c_stride;
 #pragma unroll
         for (int ta = 0; ta < NT; ++ta) {
 #pragma unroll
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
             for (int t = 0; t < 4; ++t) {
               const int vr = natvar32(ta, 4 * g + t), vc = natvar32(tb, j);
               const int hi = vr > vc ? vr : vc, lo = vr > vc ? vc : vr;
-              U[ta * NB + tb][t] = Gp[hi + (size_t)lo * a.G_ld];
+              U[ta * NB + tb][t] = Gp[hi + (size_t)lo * ka->G_ld];
             }
           }
         }
@@ -813,7 +818,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
 #pragma unroll
       for (int c = 0; c < NT; ++c) {  // [A_eq^T] tile column
 #pragma unroll
-        for (int t = 0; t < 4; ++t) U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)natvar32(c, 4 * g + t) * a.A_ld] : 0.0f;
+        for (int t = 0; t < 4; ++t) U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)natvar32(c, 4 * g + t) * ka->A_ld] : 0.0f;
       }
       lds_fence32();
       float r_pi = 0.0f, r_comp = 0.0f;
@@ -865,19 +870,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
         n_rpi2 = wave_sum_f32(r_pi * r_pi);
       }
       if (residual_mode) {  // r_ = [r_d | r_comp | r_pe | r_pi] (qp.cc:391-420) and the four norms of ComputeErrors (qp.cc:423-437)
-        float* ro = (float*)a.r_out + p * a.r_out_stride;
+        float* ro = (float*)ka->r_out + p * ka->r_out_stride;
         if (g == 0) {
 #pragma unroll
           for (int c = 0; c < NT; ++c) ro[natvar32(c, j)] = r_d[c];
           if (j < k) ro[N + m + j] = r_pe;
         }
         if (lane < m) { ro[N + lane] = r_comp; ro[N + m + k + lane] = r_pi; }
-        if (a.kkt_out) {
+        if (ka->kkt_out) {
           float kq[4];
           kkt_errors_sq(mu, kq);
           if (!include_ineq) { kq[1] = 0.0f; kq[3] = 0.0f; }
           const float e0 = sqrtf(kq[0]), e1 = sqrtf(kq[1]), e2 = sqrtf(kq[2]), e3 = sqrtf(kq[3]);
-          if (lane == 0) { float* ko = (float*)a.kkt_out + 4 * p; ko[0] = e0; ko[1] = e1; ko[2] = e2; ko[3] = e3; }
+          if (lane == 0) { float* ko = (float*)ka->kkt_out + 4 * p; ko[0] = e0; ko[1] = e1; ko[2] = e2; ko[3] = e3; }
         }
         break;
       }
@@ -898,17 +903,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
           }
           float kmax2 = kf[0];                                      // KKTError::Max() squared
           kmax2 = kf[1] > kmax2 ? kf[1] : kmax2; kmax2 = kf[2] > kmax2 ? kf[2] : kmax2; kmax2 = kf[3] > kmax2 ? kf[3] : kmax2;
-          const float tol = (float)sp.termination_kkt_tol;
-          if (kmax2 < tol * tol && cur_mu < (float)sp.termination_complementarity_tol) {  // qp.cc:132-137
+          const float tol = (float)ka->sp.termination_kkt_tol;
+          if (kmax2 < tol * tol && cur_mu < (float)ka->sp.termination_complementarity_tol) {  // qp.cc:132-137
             term = MO_SATISFIED_KKT_TOL;
             break;
           }
-          if (kmax2 <= mu * mu || !sp.decrease_mu_only_on_small_error) {                   // qp.cc:140-146 (mu > 0)
-            if (sp.barrier_strategy == MO_FIXED_DECREASE) mu *= (float)sp.sigma;
-            else mu = (float)sp.sigma * cur_mu;
+          if (kmax2 <= mu * mu || !ka->sp.decrease_mu_only_on_small_error) {                   // qp.cc:140-146 (mu > 0)
+            if (ka->sp.barrier_strategy == MO_FIXED_DECREASE) mu *= (float)ka->sp.sigma;
+            else mu = (float)ka->sp.sigma * cur_mu;
           }
         }
-        if (it >= sp.max_iterations) break;                          // MAX_ITERATIONS, qp.cc:149
+        if (it >= ka->sp.max_iterations) break;                          // MAX_ITERATIONS, qp.cc:149
         if (iter_out) {                                              // kkt_prev is only ever recorded, qp.cc:118
           float ki[4];
           kkt_errors_sq(mu, ki);
@@ -920,6 +925,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
         }
       }
       // ---------------------------------------------------------------- part B: right-hand side, factorisation, direction
+      ka = fresh_args32();
       const bool predictor_pass = use_pc && !guess_pass;
       const float mu_step = m > 0 ? (predictor_pass ? 0.0f : mu) : 0.0f;  // qp.cc:165-187
       float aff = 0.0f, cs_inv = 1.0f;  // aff = ds_aff dz_aff (qp.cc:341), set by the predictor
@@ -1071,14 +1077,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
       ++it;
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
-        if (a.delta) {
-          float* dp = (float*)a.delta + p * a.delta_stride;
+        if (ka->delta) {
+          float* dp = (float*)ka->delta + p * ka->delta_stride;
           for (int i = lane; i < N; i += 64) dp[i] = tmp[i];  // dx, natural order
           if (lane < m) { dp[N + lane] = dsv; dp[N + m + k + lane] = dzv; }
           if (g == 0 && j < k) dp[N + m + j] = dyv;
         }
-        if (a.ip_out && lane == 0) {
-          float* ip = (float*)a.ip_out + p * MO_IP_RECORD;
+        if (ka->ip_out && lane == 0) {
+          float* ip = (float*)ka->ip_out + p * MO_IP_RECORD;
           ip[0] = ip_mu; ip[1] = ap; ip[2] = ad;
           ip[3] = probe_p; ip[4] = probe_d; ip[5] = mu_aff;
         }
@@ -1097,12 +1103,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     }
     const float ymin = row_min_f32((j < k) ? yv : INFINITY), yabs = -row_min_f32((j < k) ? -fabsf(yv) : INFINITY);
     if (lane == 0) {
-      if (a.termination) a.termination[p] = term;
-      if (a.num_iterations) a.num_iterations[p] = it;
-      if (a.status) a.status[p] = st;
-      if (a.lagrange) {  // qp.cc:539-546
-        ((float*)a.lagrange)[2 * p] = k > 0 ? ymin : nanf32;
-        ((float*)a.lagrange)[2 * p + 1] = k > 0 ? yabs : nanf32;
+      if (ka->termination) ka->termination[p] = term;
+      if (ka->num_iterations) ka->num_iterations[p] = it;
+      if (ka->status) ka->status[p] = st;
+      if (ka->lagrange) {  // qp.cc:539-546
+        ((float*)ka->lagrange)[2 * p] = k > 0 ? ymin : nanf32;
+        ((float*)ka->lagrange)[2 * p + 1] = k > 0 ? yabs : nanf32;
       }
     }
     wait_vmcnt32<0>();  // nothing of this problem's ring traffic is left in flight (a pass may leave through a break)
