@@ -203,7 +203,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
   const unsigned vec_base = ring_base + D * SLOT;
 
-  const int k = a.k, m = a.m, m_r = a.m_r;
+  // MO_STEP_NO_INEQUALITIES (SolveForUpdateNoInequalities, qp.cc:366-386): the constraints take no part (m = 0 below); the state and direction
+  // vectors keep their [x | s(m_lay) | y | z(m_lay)] layout, ds = dz = 0 and both step lengths are 1.
+  const int m_lay = a.m;
+  const bool no_ineq = (a.flags & MO_STEP_NO_INEQUALITIES) != 0;
+  const int k = a.k, m = no_ineq ? 0 : a.m, m_r = a.m_r;
   const int nsteps = m_r >> 2;
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       dma_words(vp + N + m + k, vec_base + (3 * N + 192) * 4, m, lane);
     }
     if (k > 0) {
-      dma_words(vp + N + m, vec_base + (3 * N + 320) * 4, k, lane);
+      dma_words(vp + N + m_lay, vec_base + (3 * N + 320) * 4, k, lane);
       dma_words((const float*)ka->b + p * ka->b_stride, vec_base + (3 * N + 336) * 4, k, lane);
     }
 
@@ -328,7 +332,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= N));
     if (bad_index) cvar = 0;
     const bool slack_bad = __any((lane < m) && !(cs > 0.0f));
-    const bool any_bad_index = __any(bad_index);
+    bool any_bad_index = __any(bad_index);
+    if (no_ineq && m_lay > 0) {  // the index check of Setup (qp.cc:70-72) does not depend on the flag
+      bool bad = false;
+      const int* cvp = ka->cons_var + p * ka->cons_stride;
+      for (int ix = lane; ix < m_lay; ix += 64) { const int v = cvp[ix]; bad = bad || v < 0 || v >= N; }
+      any_bad_index = __any(bad);
+    }
     const float cs_inv = rcp_f32(cs);
     if (lane < m) {
       const float zs = cz * cs_inv;
@@ -445,7 +455,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
 #pragma unroll
       for (int c = 0; c < NT; ++c) outv[c] = st == MO_STATUS_OK ? dxv[c] : nanv;
       stv32<NT>(dp, j, outv);
-      if (j < k) dp[N + m + j] = st == MO_STATUS_OK ? dyv : nanv;
+      if (j < k) dp[N + m_lay + j] = st == MO_STATUS_OK ? dyv : nanv;
+    }
+    if (no_ineq) {  // ds = dz = 0 (qp.cc:366-386 writes only dx, dy)
+      for (int ix = lane; ix < m_lay; ix += 64) { dp[N + ix] = st == MO_STATUS_OK ? 0.0f : nanv; dp[N + m_lay + k + ix] = st == MO_STATUS_OK ? 0.0f : nanv; }
     }
     if (lane < m) {
       dp[N + lane] = st == MO_STATUS_OK ? dsv : nanv;
@@ -1324,7 +1337,7 @@ bool fused_f32_supported(const KernelArgs& a, int dtype) {
     }
     return true;
   }
-  if (a.flags != 0 || a.mode != MODE_STEP) return false;
+  if ((a.flags & ~MO_STEP_NO_INEQUALITIES) != 0 || a.mode != MODE_STEP) return false;
   if (!a.delta || !a.J) return false;
   if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
   if (!aligned16_f32(a.J) || (a.J_stride & 3)) return false;

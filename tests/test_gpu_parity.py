@@ -654,6 +654,17 @@ def test_fused_f32_shapes(n, k, m, m_r):
     err = rel_inf_rows(delta.double().cpu().numpy(), ref)
     assert err.max() < TOL32, err.max()
     np.testing.assert_allclose(alpha.double().cpu().numpy(), ref_alpha, atol=5e-3)
+    # MO_STEP_NO_INEQUALITIES (SolveForUpdateNoInequalities, qp.cc:366-386) runs on the fp32 fused kernel as well: dx, dy of the problem without its
+    # inequalities, ds = dz = 0, both step lengths 1 -- against the oracle on the same problem with m = 0
+    d0, a0, st0 = s.NewtonStep(T(mu, dt), 0.995, include_inequalities=False)
+    assert torch.all(st0 == 0) and torch.all(a0 == 1.0)
+    d0 = d0.double().cpu().numpy()
+    assert np.all(d0[:, n:n + m] == 0) and np.all(d0[:, n + m + k:] == 0)
+    vars0 = np.concatenate([x, y], axis=1)
+    ref0, _, rs0, _ = orc.batched_newton_step(n, k, 0, J=J, r=r, lam=lam, A_eq=A if k else None, b_eq=b if k else None, vars_=vars0, mu=mu)
+    assert np.all(rs0 == 0)
+    got0 = np.concatenate([d0[:, :n], d0[:, n + m:n + m + k]], axis=1)
+    assert rel_inf_rows(got0, ref0).max() < TOL32
 
 
 def test_fused_f32_status_words():
