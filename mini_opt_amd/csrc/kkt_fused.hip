@@ -1184,8 +1184,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
       if (j == kRC) v = (e0 + g + 4 * t < k) ? -bb[e0 + g + 4 * t] : 0.0;
       if (g + 4 * t == kRC) v = (e0 + j < k) ? -bb[e0 + j] : 0.0;
       U[LT * NB + LT][t] = v;
-      if constexpr (NY == 2) {          // the full y tile in front of it: right-hand side -b_eq[0 .. 15] in column kRC of tile (NT, LT)
-        if (j == kRC) U[NT * NB + LT][t] = -bb[g + 4 * t];
+#pragma unroll
+      for (int q = 0; q < NY - 1; ++q) {   // the full y tiles in front of it: right-hand side -b_eq[16 q .. 16 q + 15] in column kRC of tile (NT + q, LT)
+        if (j == kRC) U[(NT + q) * NB + LT][t] = -bb[16 * q + g + 4 * t];
       }
     }
     const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
@@ -1972,9 +1973,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         if (j == kRC) v = ysm[YN + 16 * (NY - 1) + g + 4 * t];
         if (g + 4 * t == kRC) v = -r_pe[NY - 1];
         U[LT * NB + LT][t] = v;
-        if constexpr (NY == 2) {     // the full y tile in front of it: its right-hand side rides in column kRC of tile (NT, LT)
-          U[NT * NB + NT][t] = 0.0;
-          U[NT * NB + LT][t] = (j == kRC) ? ysm[YN + g + 4 * t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NY - 1; ++q) {   // the full y tiles in front of it: their right-hand sides ride in column kRC of the tiles (NT + q, LT)
+          U[(NT + q) * NB + NT + q][t] = 0.0;
+          U[(NT + q) * NB + LT][t] = (j == kRC) ? ysm[YN + 16 * q + g + 4 * t] : 0.0;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -2170,7 +2172,12 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.mode != MODE_SOLVE && a.mode != MODE_ITERATE && a.mode != MODE_STEP && a.mode != MODE_RESIDUAL) return false;
   if (a.mode == MODE_RESIDUAL && !a.r_out) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
-  if (a.k > 31 || a.m < 0) return false;  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31
+  if (a.m < 0) return false;
+  if (a.k > 31) {  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31, three / four (kkt_fused_ny34.hip) up to 47 / 63 on the 32 / 64 grids
+    if (a.k > 63 || a.n > 64 || a.m > 128) return false;
+    if (a.mode == MODE_LINEARIZE) return false;
+    if (a.J && (fused_needs_gather(a) || (a.n & 1))) return false;  // packed even-n J or (G, c) only
+  }
   // up to four constraint slots per lane: m <= 256 (beyond 128, and beyond 64 for Solve / Iterate on the 96 / 128 grids: kkt_fused_mc4.hip)
   if (a.m > 256) return false;
   if (a.m > 128 && (a.k > 15 || (a.J && (a.n & 1)))) return false;  // the two-y-tile and the flat-stream kernels carry at most two / one slot
@@ -2229,6 +2236,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   if (a.mode != MODE_LINEARIZE && a.k <= 15 && !fused_needs_gather(a) && !(a.J && (a.n & 1)) &&
       (a.m > 128 || (a.m > 64 && a.n > 64 && a.mode != MODE_STEP)))
     return launch_fused_mc4(a, num_cus, stream);
+  if (a.mode != MODE_LINEARIZE && a.k > 31) return launch_fused_ny34(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && a.k > 15) return launch_fused_ny2(a, num_cus, stream);
   if (fused_needs_gather(a) || (a.mode == MODE_LINEARIZE && (a.n & 1))) return launch_fused_gather(a, num_cus, stream);
 #endif

@@ -82,6 +82,7 @@ hipError_t launch_fused(const KernelArgs& a, int dtype, int num_cus, hipStream_t
 bool fused_needs_gather(const KernelArgs& a);  // J-level input in a layout only the per-lane gather stream takes
 hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t stream);  // kkt_fused_gather.hip
 hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream);     // kkt_fused_ny2.hip: 16 <= k <= 31
+hipError_t launch_fused_ny34(const KernelArgs& a, int num_cus, hipStream_t stream);    // kkt_fused_ny34.hip: 32 <= k <= 63 on the 32 / 64 grids
 hipError_t launch_fused_mc4(const KernelArgs& a, int num_cus, hipStream_t stream);     // kkt_fused_mc4.hip: 128 < m <= 256; Solve with m > 64 on the 96 / 128 grids
 bool fused_tiny_supported(const KernelArgs& a);                                          // kkt_fused_tiny.hip: n + k <= 15, m <= 64 (a subset of fused_supported)
 hipError_t launch_fused_tiny(const KernelArgs& a, int num_cus, hipStream_t stream);

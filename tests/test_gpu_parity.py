@@ -946,6 +946,23 @@ def test_fused_two_y_tiles_vs_generic_random_shapes():
         _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=True, kkt_tol=1e-6)
 
 
+def test_fused_three_and_four_y_tiles_vs_generic_random_shapes():
+    """32 <= k <= 63 equality constraints on the 32 / 64 tile grids: the fused kernels carry three / four y tiles (kkt_fused_ny34.hip; packed
+    even-n J or (G, c), m <= 128).  Twenty random shapes against the generic kernel (pinned to the oracle elsewhere; the knife-edge rule
+    with the oracle as referee for the Solves), plus the corner shapes k = 32, 47, 48, 63."""
+    rng = np.random.default_rng(4041)
+    shapes = [(64, 32), (64, 47), (64, 48), (64, 63), (36, 32), (40, 33)]
+    for i in range(14):
+        k = int(rng.integers(32, 60))
+        n = 2 * int(rng.integers((k + 5) // 2, 33))             # even n in [k + 4, 64]: the equalities leave the inequalities something to do
+        shapes.append((n, k))                                    # (k = n fixes x: with inequalities on top there is no trajectory to compare, DESIGN section 2)
+    for n, k in shapes:
+        level = rng.choice(["J", "QP"])
+        m = int(rng.integers(0, 129))
+        m_r = int(rng.integers(1, 160))
+        _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=True, kkt_tol=1e-6)
+
+
 @pytest.mark.parametrize("level,n,k,m,m_r", [("J", 15, 0, 0, 15), ("J", 13, 2, 64, 64), ("J", 2, 1, 1, 1), ("J", 8, 7, 5, 3), ("QP", 14, 1, 64, 0),
                                                ("QP", 2, 0, 0, 0), ("J", 8, 2, 4, 16), ("J", 5, 0, 64, 64), ("QP", 9, 6, 30, 0)])
 def test_one_tile_kernel_at_its_boundaries(level, n, k, m, m_r):

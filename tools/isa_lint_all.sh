@@ -7,11 +7,11 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -mllvm -amdgpu-at
 OUT=${ISA_LINT_DIR:-/tmp/isa_lint}
 mkdir -p $OUT
 rc=0
-for f in kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_mc4 kkt_fused_tiny kkt_fused_f32 nls_kernels; do
+for f in kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_ny34 kkt_fused_mc4 kkt_fused_tiny kkt_fused_f32 nls_kernels; do
   ( /opt/rocm/bin/hipcc $FLAGS -S --cuda-device-only -o $OUT/$f.s $SRC/$f.hip 2>/dev/null ) &
 done
 wait
-for f in kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_mc4 kkt_fused_tiny kkt_fused_f32 nls_kernels; do
+for f in kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_ny34 kkt_fused_mc4 kkt_fused_tiny kkt_fused_f32 nls_kernels; do
   python3 $ROOT/tools/isa_lint.py $OUT/$f.s | tail -1 | sed "s#^#$f.hip: #"
   python3 $ROOT/tools/isa_lint.py $OUT/$f.s > /dev/null || rc=1
   grep -c "s_swappc_b64" $OUT/$f.s | sed "s#^#$f.hip: device function calls (s_swappc_b64): #"
