@@ -553,7 +553,7 @@ template <int SW> __device__ inline bool sweep_tile(d4& T, int npiv, int g, int 
 // scalar unit: base + column part; one VGPR holds the lane part g * row_stride + 2j * column_stride).  2 NT + 1 DMAs per group, operand c
 // at dwords [2c][lane] and [2c+1][lane] of the slot.  The memory system sees 4-byte pieces: this is the flexible path, not the fast one.
 constexpr int JMODE_VECTOR = 0, JMODE_FLAT = 1, JMODE_GATHER = 2;
-template <int NT, int D, int JMODE = JMODE_VECTOR, int NY = 1>
+template <int NT, int D, int JMODE = JMODE_VECTOR, int NY = 1, bool ROW0 = true>
 struct JStream {
   static constexpr bool FLAT = JMODE == JMODE_FLAT, GATHER = JMODE == JMODE_GATHER;
   static constexpr int N = 16 * NT, NB = NT + NY, NH = NT / 2, NI = GATHER ? 2 * NT : (FLAT ? N / 8 : NH), DPS = NI + 1, SLOT = NH * 1024 + 64;
@@ -682,9 +682,38 @@ struct JStream {
     for (int ta = 0; ta < NT; ++ta) {
       cpart[ta] = fma(ops[ta], rq, cpart[ta]);
 #pragma unroll
-      for (int tb = ta; tb < NT; ++tb)
-        U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+      for (int tb = ta; tb < NT; ++tb) jtj_mfma(U[ta * NB + tb], ops[ta], ops[tb], ta);
     }
+  }
+  // One J^T J MFMA.  On the 128 grid the 36 accumulator tiles (288 registers) exceed the 256 AGPRs, and with one wave per SIMD hipcc selects
+  // the AGPR form for every MFMA result: it shuttled five tiles through v_accvgpr_write / read around their MFMAs in every 4-row group (320
+  // moves per 144 MFMAs).  Tile row 0 is never an MFMA result again after this stream (block step 0 only reads it), so its eight MFMAs are
+  // written as inline assembly with a VGPR accumulator: 28 tiles stay in AGPRs, 8 in VGPRs, no moves.  The compiler cannot see the MFMA
+  // inside the asm, so the wait states it inserts around MFMAs are ours to supply: `s_nop 3` in front (VALU write of an operand or of EXEC
+  // -> MFMA read) and finish() behind the stream (16-pass DGEMM result -> VALU / LDS / memory access: 18).  What cannot be supplied from
+  // here are wait states in front of an access the COMPILER places between two of these MFMAs -- a spill of a row-0 tile above all.  The
+  // kernels with a second y tile on this grid (55 tiles, heavy spilling) did exactly that and their Solve differed from run to run, so
+  // they keep the builtin; for the others tools/isa_lint.py checks every listing: no instruction but an MFMA may touch the destination
+  // registers of a VGPR-form MFMA inside the blocks that hold one.
+#ifdef MO_ROW0_ALL_NY   // diagnostic: also with a second y tile (what tools/isa_lint.py flags there is the reason it is off)
+  static constexpr bool ROW0_VGPR = NT == 8 && ROW0;
+#elif !defined(MO_NO_ROW0_VGPR)
+  static constexpr bool ROW0_VGPR = NT == 8 && NY == 1 && ROW0;
+#else
+  static constexpr bool ROW0_VGPR = false;
+#endif
+#ifndef MO_ROW0_ASM_QUAL
+#define MO_ROW0_ASM_QUAL
+#endif
+#ifndef MO_ROW0_PREFIX
+#define MO_ROW0_PREFIX "s_nop 3\n\t"
+#endif
+  __device__ static inline void jtj_mfma(d4& acc, double a, double b, int ta) {
+    if (ROW0_VGPR && ta == 0) asm MO_ROW0_ASM_QUAL (MO_ROW0_PREFIX "v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  __device__ static inline void finish() {
+    if (ROW0_VGPR) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // 16-pass DGEMM result -> VALU read / write: 18 wait states at most
   }
 #define MO_FOR_SLOTS(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
   __device__ inline void prologue() {  // fill the ring
@@ -728,10 +757,10 @@ struct JStream {
       for (int ta = 0; ta < NT; ++ta) {
         cpart[ta] = fma(ops[ta], rq, cpart[ta]);
 #pragma unroll
-        for (int tb = ta; tb < NT; ++tb)
-          U[ta * NB + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+        for (int tb = ta; tb < NT; ++tb) jtj_mfma(U[ta * NB + tb], ops[ta], ops[tb], ta);
       }
     }
+    finish();
   }
 #undef MO_FOR_SLOTS
 };
@@ -1980,7 +2009,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifndef MO_SOLVE_NO_LOOKAHEAD
+      // the look-ahead elimination (bit-identical results) on the 64 grid: no gain in the step kernel at three waves per SIMD (DESIGN.md
+      // section 8), but the Solve kernel runs two and its cached passes are chains: 9.38 -> 9.55 M solves/s, 11.86 -> 12.03 M predictor-corrector
+      bool elim_ok;
+      if constexpr (NY == 1 && NT == 4) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
+      else elim_ok = block_eliminate<NT, SW, NY>(U, k, g, j);
+      if (!elim_ok) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+#else
       if (!block_eliminate<NT, SW, NY>(U, k, g, j)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+#endif
       double xb[NB];
       back_substitute<NT, NY>(U, k, j, xb);  // xb[c] = dx (permuted), xb[NT + q] = -dy
       double dyv[NY], dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;

@@ -90,6 +90,7 @@ template <typename T> struct Ws {
   T* rhs; T* invd;                     // P each
   T* ca; T* cb;                        // m each
   T* Jc; T* rc; int chunk_rows;        // J row chunk
+  int region;                          // LARGE: elements of the panel region that starts at Jc
   T* red;                              // 16 scalars
   int* cv;                             // m
   int* iflag;                          // 8
@@ -117,21 +118,34 @@ __host__ __device__ inline size_t ws_elems(int n, int k, int m, int m_r) {
 // workspace of the workgroup (P x ldh, column-major, plan-owned, L2-resident: one per workgroup of the persistent grid), everything else stays
 // in LDS.  The J row chunk and the factorisation's column panel share one LDS region (they are never live together).
 __host__ __device__ inline int large_ld(int P) { return (P + 1) & ~1; }
+#ifndef MO_LARGE_NB_MAX
+#define MO_LARGE_NB_MAX 32
+#endif
 __host__ __device__ inline int panel_cols_for(int n, int k, int m, int m_r, int elem) {
   // widest panel (32 / 16 / 8 columns of P | 1 rows) that fits beside the vectors
   const int P = n + k, V = n + 2 * m + k;
   const size_t vec = (4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + 16) * elem + (size_t)(m + 8) * sizeof(int) + 64;
-  for (int nb = 32; nb >= 8; nb >>= 1)
+  // two workgroups per CU count for more than a wide panel (n = 256, k = 40, m = 128: 32 columns and one workgroup per CU 19.9 ms for 2 048
+  // steps, 16 columns and two 14.0 ms, 8 columns and three 22.4 ms): 32 or 16 columns if two workspaces fit the LDS, else the widest that fits
+  for (int nb = MO_LARGE_NB_MAX; nb >= 16; nb >>= 1)
+    if (2 * (vec + (size_t)(P | 1) * nb * elem + 64) <= 160 * 1024) return nb;
+  for (int nb = MO_LARGE_NB_MAX; nb >= 8; nb >>= 1)
     if (vec + (size_t)(P | 1) * nb * elem <= 160 * 1024) return nb;
   return 0;
 }
 template <typename T>
 __host__ __device__ inline size_t ws_elems_large(int n, int k, int m, int m_r) {
   const int P = n + k, V = n + 2 * m + k;
-  const int cr = chunk_rows_for(n, m_r, (int)sizeof(T));
   const int nb = panel_cols_for(n, k, m, m_r, (int)sizeof(T));
-  const size_t chunk = (size_t)cr * n + cr, panel = (size_t)(P | 1) * nb;
-  return 4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + (chunk > panel ? chunk : panel) + 16;
+  return 4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + (size_t)(P | 1) * nb + 16;
+}
+// rows of J per chunk: as many as the panel region holds (each chunk costs one read-modify-write of the whole lower triangle of G in the
+// global workspace, so few large chunks: 37 rows instead of 4 at n = 256 took the kernel's HBM traffic from 96 GB to a quarter of it)
+__host__ __device__ inline int chunk_rows_large(int n, int k, int m, int m_r, int elem) {
+  if (m_r <= 0) return 0;
+  const int P = n + k;
+  int cr = (int)(((size_t)(P | 1) * panel_cols_for(n, k, m, m_r, elem)) / (size_t)(n + 1));
+  return cr > m_r ? m_r : cr;
 }
 template <typename T>
 __device__ inline void carve_large(Ws<T>& w, char* smem, T* H_global, int n, int k, int m, int m_r) {
@@ -143,10 +157,10 @@ __device__ inline void carve_large(Ws<T>& w, char* smem, T* H_global, int n, int
   w.cvec = p; p += n; w.beq = p; p += k;
   w.rhs = p; p += P; w.invd = p; p += P;
   w.ca = p; p += m; w.cb = p; p += m;
-  w.chunk_rows = chunk_rows_for(n, m_r, (int)sizeof(T));
+  w.chunk_rows = chunk_rows_large(n, k, m, m_r, (int)sizeof(T));
   const int nb = panel_cols_for(n, k, m, m_r, (int)sizeof(T));
-  const size_t chunk = (size_t)w.chunk_rows * n + w.chunk_rows, panel = (size_t)(P | 1) * nb;
-  w.Jc = p; w.rc = p + (size_t)w.chunk_rows * n; p += (chunk > panel ? chunk : panel);   // (the panel overlays the J chunk)
+  w.region = (P | 1) * nb;
+  w.Jc = p; w.rc = p + (size_t)w.chunk_rows * n; p += (size_t)(P | 1) * nb;   // (the panel overlays the J chunk: chunk_rows (n + 1) <= panel)
   w.red = p; p += 16;
   w.cv = reinterpret_cast<int*>(p);
   w.iflag = w.cv + m;
@@ -275,12 +289,21 @@ __device__ inline void jtj_superblock(const Ws<T>& w, int n, int rows, int I0, i
       for (int bj = 0; bj < RN; ++bj)
         if (!DIAG || bj <= bi) acc[bi * RN + bj] += a[bi] * b[bj];
   }
+  // read-modify-write of the block in two phases: all loads first (36 round trips to the workspace in flight together; `+=` element by
+  // element made them one after the other, since the compiler must assume the stores alias the next load: 15 us per call, measured)
 #pragma unroll
   for (int bi = 0; bi < RN; ++bi)
 #pragma unroll
     for (int bj = 0; bj < RN; ++bj) {
       const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
-      if ((!DIAG || bj <= bi) && i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] += acc[bi * RN + bj];
+      if ((!DIAG || bj <= bi) && i < n && j < n && j <= i) acc[bi * RN + bj] += w.H[i + (size_t)j * w.ldh];
+    }
+#pragma unroll
+  for (int bi = 0; bi < RN; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < RN; ++bj) {
+      const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
+      if ((!DIAG || bj <= bi) && i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] = acc[bi * RN + bj];
     }
 }
 // H.lower(n x n) += J^T J, cvec = J^T r, diag += lambda; returns 0.5|r|^2 in w.red[8]   (residual.hpp:206-225,
@@ -559,11 +582,18 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
                 for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] += av[a_] * bv[b_];
             }
 #pragma unroll
+            for (int a_ = 0; a_ < 4; ++a_)   // two-phase read-modify-write (all 16 loads in flight together, see jtj_superblock)
+#pragma unroll
+              for (int b_ = 0; b_ < 4; ++b_) {
+                const int i = I0 + ti + 16 * a_, j = J0 + tj + 16 * b_;
+                if (i < tr && j <= i) acc[a_][b_] = w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] - acc[a_][b_];
+              }
+#pragma unroll
             for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
               for (int b_ = 0; b_ < 4; ++b_) {
                 const int i = I0 + ti + 16 * a_, j = J0 + tj + 16 * b_;
-                if (i < tr && j <= i) w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] -= acc[a_][b_];
+                if (i < tr && j <= i) w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] = acc[a_][b_];
               }
           }
         }
@@ -575,27 +605,69 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
   __syncthreads();
   return status;
 }
-// LARGE: (L D L^T) sol = rhs in place with H in global memory.  Forward substitution column by column over the whole workgroup (coalesced
-// column reads, one barrier per column); backward substitution as row dot products on wave 0 (column k below the diagonal is contiguous).
+// LARGE: (L D L^T) sol = rhs in place with H in global memory, in blocks of SB <= 32 columns (one round of global-memory latency per block
+// instead of one per column).  Forward: the block's SB x SB triangle is staged in LDS and solved by wave 0 with the unknowns in registers
+// (lane = row, one readlane per column); then every row below gets its SB-term update from SB independent coalesced column reads.  Backward:
+// the block's dot products with the part of the solution below it first (waves over columns, lanes over rows, SB independent reads per
+// lane), then the transposed triangle on wave 0 (lane = column).  `region` = elements of the panel region (free between factorisations).
 template <typename T>
-__device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int tid) {
-  for (int kk = 0; kk < P; ++kk) {
-    const T tk = w.rhs[kk] * w.invd[kk];
-    const T* col = w.H + (size_t)kk * w.ldh;
-    for (int i = kk + 1 + tid; i < P; i += kThreads) w.rhs[i] -= col[i] * tk;
+__device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid) {
+  int SB = 32;
+  while (SB > 1 && SB * (SB + 1) + 2 * SB > region) SB >>= 1;
+  const int ldb = SB + 1;
+  T* const dblk = w.Jc;                 // the triangle, column-major, ld = SB + 1
+  T* const tvec = dblk + SB * ldb;      // SB scaled unknowns / SB partial dot products
+  const int lane = tid & 63, wave = tid >> 6, nwaves = kThreads >> 6;
+  for (int c0 = 0; c0 < P; c0 += SB) {
+    const int wd = P - c0 < SB ? P - c0 : SB;
+    for (int idx = tid; idx < wd * wd; idx += kThreads) {
+      const int jj = idx / wd, i = idx - jj * wd;
+      dblk[i + jj * ldb] = i > jj ? w.H[(size_t)(c0 + i) + (size_t)(c0 + jj) * w.ldh] : (T)0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      T zi = lane < wd ? w.rhs[c0 + lane] : (T)0;
+      for (int jj = 0; jj < wd; ++jj) {
+        const T tj = rl(zi, jj) * w.invd[c0 + jj];
+        if (lane > jj && lane < wd) zi -= dblk[lane + jj * ldb] * tj;
+      }
+      if (lane < wd) { w.rhs[c0 + lane] = zi; tvec[lane] = zi * w.invd[c0 + lane]; }
+    }
+    __syncthreads();
+    for (int i = c0 + wd + tid; i < P; i += kThreads) {
+      const T* row = w.H + (size_t)i + (size_t)c0 * w.ldh;
+      T acc = (T)0;
+      for (int jj = 0; jj < wd; ++jj) acc += row[(size_t)jj * w.ldh] * tvec[jj];
+      w.rhs[i] -= acc;
+    }
     __syncthreads();
   }
-  if (tid < 64) {
-    for (int kk = P - 1; kk >= 0; --kk) {
-      const T* col = w.H + (size_t)kk * w.ldh;
-      T sacc = (T)0;
-      for (int i = kk + 1 + tid; i < P; i += 64) sacc += col[i] * w.rhs[i];
-      sacc = wave_sum(sacc);
-      if (tid == 0) w.rhs[kk] = (w.rhs[kk] - sacc) * w.invd[kk];
-      wave_lds_fence();
+  const int last = ((P - 1) / SB) * SB;
+  for (int c0 = last; c0 >= 0; c0 -= SB) {
+    const int wd = P - c0 < SB ? P - c0 : SB, below = c0 + wd;
+    for (int idx = tid; idx < wd * wd; idx += kThreads) {
+      const int jj = idx / wd, i = idx - jj * wd;
+      dblk[i + jj * ldb] = i > jj ? w.H[(size_t)(c0 + i) + (size_t)(c0 + jj) * w.ldh] : (T)0;
     }
+    for (int jj = wave; jj < wd; jj += nwaves) {
+      const T* col = w.H + (size_t)(c0 + jj) * w.ldh;
+      T sacc = (T)0;
+      for (int i = below + lane; i < P; i += 64) sacc += col[i] * w.rhs[i];
+      sacc = wave_sum(sacc);
+      if (lane == 0) tvec[jj] = sacc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      T v = lane < wd ? w.rhs[c0 + lane] - tvec[lane] : (T)0, mine = (T)0;
+      for (int i = wd - 1; i >= 0; --i) {
+        const T xi = rl(v, i) * w.invd[c0 + i];
+        if (lane == i) mine = xi;
+        if (lane < i) v -= dblk[i + lane * ldb] * xi;
+      }
+      if (lane < wd) w.rhs[c0 + lane] = mine;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 // Reduced-KKT assembly (Sigma on the diagonal, qp.cc:293-298) + LDL^T.  Returns MO_STATUS_*.
@@ -669,7 +741,7 @@ __device__ MO_INLINE void solve_for_update(const Ws<T>& w, int n, int k, int m, 
   for (int q = tid; q < k; q += kThreads) w.rhs[n + q] = -r_pe[q];
   __syncthreads();
   if constexpr (LARGE) {
-    block_solve(w, P, tid);
+    block_solve(w, P, w.region, tid);
   } else {
     if (tid < 64) wave_solve(w, P, tid);
     __syncthreads();

@@ -138,3 +138,21 @@ def test_isa_lint_flags_the_copy_in_front_of_an_exec_restore():
     assert len(hits) == 1 and "v_accvgpr_write_b32 a85, v166" in hits[0][3]
     good = bad.replace("\tv_accvgpr_write_b32 a85, v166\n", "").replace("\ts_or_b64 exec, exec, s[0:1]\n", "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a85, v166\n")
     assert "v_accvgpr_write_b32" in good and lint.lint_text(good) == []
+
+
+def test_isa_lint_flags_an_access_to_the_result_of_an_inline_assembly_mfma():
+    """tools/isa_lint.py, second check: hipcc cannot see an MFMA inside inline assembly, so a spill of its VGPR result right behind it (what
+    the 128-grid kernels with a second y tile got) carries no wait states.  Hand-written listing fragments."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    asm_mfma = "\t;;#ASMSTART\n\ts_nop 3\n\tv_mfma_f64_16x16x4_f64 v[40:47], v[2:3], v[4:5], v[40:47]\n\t;;#ASMEND\n"
+    spill = "\tscratch_store_dwordx4 off, v[44:47], off offset:16 ; 16-byte Folded Spill\n"
+    other = "\tv_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[4:5], a[0:7]\n\tscratch_store_dwordx4 off, v[48:51], off offset:32\n"
+    head = "kernel_a:\n"
+    hits = lint.lint_asm_mfma(head + asm_mfma + other + spill)
+    assert len(hits) == 1 and "v[44:47]" in hits[0][3] and hits[0][2] == "kernel_a"
+    assert lint.lint_asm_mfma(head + asm_mfma + other + "\ts_nop 15\n\ts_nop 3\n" + spill) == []          # the wait states are there
+    assert lint.lint_asm_mfma(head + asm_mfma.replace(";;#ASMSTART", "").replace(";;#ASMEND", "") + spill) == []  # a builtin MFMA: hipcc's business
+    assert lint.lint_asm_mfma(head + asm_mfma + "\tv_mfma_f64_16x16x4_f64 a[8:15], v[40:41], v[4:5], a[8:15]\n") == []  # MFMAs may read it

@@ -1,4 +1,4 @@
-// phase_timer.hip -- DIAGNOSTIC build of the fused kernel with s_memtime stamps at phase boundaries (never shipped:
+// phase_timer_generic.hip [n batch k m m_r] -- DIAGNOSTIC build of the generic kernel (LDS-resident and LARGE) with s_memtime stamps at phase boundaries (never shipped:
 // the product library is built without MO_FUSED_STAMPS).  Prints the share of wave time per phase.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DMO_FUSED_STAMPS tools/phase_timer.hip -o tools/phase_timer
 #include "../mini_opt_amd/csrc/kkt_fused.hip"
@@ -31,8 +31,8 @@ __global__ void fill_cons(int* var, double* a, double* b, double* vars, int n, i
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 64;
-  const int k = n / 8, m = n / 2, m_r = 2 * n;
   const size_t batch = argc > 2 ? atoll(argv[2]) : 65536;
+  const int k = argc > 3 ? atoi(argv[3]) : n / 8, m = argc > 4 ? atoi(argv[4]) : n / 2, m_r = argc > 5 ? atoi(argv[5]) : 2 * n;
   const int V = n + 2 * m + k;
   double *J, *r, *A, *b, *ca, *cb, *vars, *mu, *delta, *alpha; int *cv, *status; unsigned long long* dbg;
   CK(hipMalloc(&J, batch * m_r * n * 8)); CK(hipMalloc(&r, batch * m_r * 8)); CK(hipMalloc(&A, batch * k * n * 8));
@@ -54,6 +54,13 @@ int main(int argc, char** argv) {
   a.vars = vars; a.vars_stride = V; a.mu = mu; a.mu_stride = 1; a.tau = 0.995;
   a.delta = delta; a.delta_stride = V; a.alpha = alpha; a.status = status; a.debug = dbg; a.ticket = ticket;
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  if (mo::generic_needs_large(a, 8)) {  // H in a global workspace per workgroup of the persistent grid (what mo_api.hip's launch_chosen allocates)
+    const size_t per_wg = mo::generic_large_workspace_elems(a);
+    const size_t wgs = (size_t)mo::generic_large_grid(a, 8, prop.multiProcessorCount);
+    CK(hipMalloc(&a.H_work, wgs * per_wg * 8));
+    a.H_work_stride = (long long)per_wg;
+    printf("LARGE path: %zu workgroups, %zu B of H each, %zu B of LDS\n", wgs, per_wg * 8, mo::generic_large_lds_bytes(a, 8));
+  }
 
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 3; ++rep) {
