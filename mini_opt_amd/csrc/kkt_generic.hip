@@ -127,8 +127,10 @@ __host__ __device__ inline int panel_cols_for(int n, int k, int m, int m_r, int 
   const size_t vec = (4 * (size_t)V + n + k + 2 * (size_t)P + 2 * (size_t)m + 16) * elem + (size_t)(m + 8) * sizeof(int) + 64;
   // two workgroups per CU count for more than a wide panel (n = 256, k = 40, m = 128: 32 columns and one workgroup per CU 19.9 ms for 2 048
   // steps, 16 columns and two 14.0 ms, 8 columns and three 22.4 ms): 32 or 16 columns if two workspaces fit the LDS, else the widest that fits
+#ifndef MO_LARGE_NO_PAIR
   for (int nb = MO_LARGE_NB_MAX; nb >= 16; nb >>= 1)
     if (2 * (vec + (size_t)(P | 1) * nb * elem + 64) <= 160 * 1024) return nb;
+#endif
   for (int nb = MO_LARGE_NB_MAX; nb >= 8; nb >>= 1)
     if (vec + (size_t)(P | 1) * nb * elem <= 160 * 1024) return nb;
   return 0;
@@ -177,6 +179,7 @@ __device__ inline void carve(Ws<T>& w, char* smem, int n, int k, int m, int m_r)
   w.rhs = p; p += P; w.invd = p; p += P;
   w.ca = p; p += m; w.cb = p; p += m;
   w.chunk_rows = chunk_rows_for(n, m_r, (int)sizeof(T));
+  w.region = 0;
   w.Jc = p; p += (size_t)w.chunk_rows * n; w.rc = p; p += w.chunk_rows;
   w.red = p; p += 16;
   w.cv = reinterpret_cast<int*>(p);
@@ -221,7 +224,12 @@ template <typename T>
 __device__ MO_INLINE void load_qp(const Ws<T>& w, int n, int k, const T* G, int G_ld, const T* c, const T* A, int A_ld,
                         const T* b, int tid) {
   const int P = n + k;
-  for (int idx = tid; idx < P * w.ldh; idx += kThreads) w.H[idx] = (T)0;
+  if (w.region > 0) {   // LARGE (H in global memory): only the y-y block needs zeros -- G's lower triangle is written below or by accumulate_jtj
+    for (int j = n; j < P; ++j)    // (plain stores there), the A rows below, and nothing reads above the diagonal
+      for (int i = n + tid; i < P; i += kThreads) w.H[i + (size_t)j * w.ldh] = (T)0;
+  } else {
+    for (int idx = tid; idx < P * w.ldh; idx += kThreads) w.H[idx] = (T)0;
+  }
   __syncthreads();
   if (G) {
     for (int j = 0; j < n; ++j)
@@ -264,22 +272,21 @@ __device__ inline void jtj_tile_rows_impl(const Ws<T>& w, int n, int rows, int t
       if (i < n && j <= i) w.H[i + (size_t)j * w.ldh] += acc[bi * (bi + 1) / 2 + bj];
     }
 }
-// LARGE: the same register tiling over 96 x 96 super-blocks of G (16 x 16 threads x 6 x 6 blocks), lower block triangle only; G is in global memory.
+// LARGE: the same register tiling over 96 x 96 super-blocks of G (16 x 16 threads x 6 x 6 blocks), lower block triangle only.  G is in global
+// memory, so the super-block is the OUTER loop: its 36 accumulators stay in registers over all rows of J and are stored once (first version:
+// chunk of rows outside, read-modify-write of G per chunk -- 9 MB of workspace traffic per problem at n = 256, the kernel's bound).  Per
+// super-block only the columns [I0, I0 + wi) and [J0, J0 + wj) of J are staged (wj = 0 on the diagonal), `rows` of them at a time.
 template <typename T, bool DIAG>
-__device__ inline void jtj_superblock(const Ws<T>& w, int n, int rows, int I0, int J0, int tid) {
+__device__ inline void jtj_superblock_rows(const T* Jc, int wc, int wi, int wj, int rows, int ti, int tj, T (&acc)[36]) {
   constexpr int TG = 16, RN = 6;
-  const int ti = tid & (TG - 1), tj = tid / TG;
-  T acc[RN * RN];
-#pragma unroll
-  for (int e = 0; e < RN * RN; ++e) acc[e] = (T)0;
   int ic[RN], jc[RN];
 #pragma unroll
-  for (int b = 0; b < RN; ++b) {
-    ic[b] = I0 + ti + TG * b < n ? I0 + ti + TG * b : n - 1;
-    jc[b] = J0 + tj + TG * b < n ? J0 + tj + TG * b : n - 1;
+  for (int b = 0; b < RN; ++b) {   // clamped local column indices: out-of-range operands are read (in bounds) and their results never stored
+    ic[b] = ti + TG * b < wi ? ti + TG * b : wi - 1;
+    jc[b] = DIAG ? (tj + TG * b < wi ? tj + TG * b : wi - 1) : wi + (tj + TG * b < wj ? tj + TG * b : wj - 1);
   }
   for (int q = 0; q < rows; ++q) {
-    const T* row = w.Jc + (size_t)q * n;
+    const T* row = Jc + (size_t)q * wc;
     T a[RN], b[RN];
 #pragma unroll
     for (int e = 0; e < RN; ++e) { a[e] = row[ic[e]]; b[e] = row[jc[e]]; }
@@ -289,22 +296,67 @@ __device__ inline void jtj_superblock(const Ws<T>& w, int n, int rows, int I0, i
       for (int bj = 0; bj < RN; ++bj)
         if (!DIAG || bj <= bi) acc[bi * RN + bj] += a[bi] * b[bj];
   }
-  // read-modify-write of the block in two phases: all loads first (36 round trips to the workspace in flight together; `+=` element by
-  // element made them one after the other, since the compiler must assume the stores alias the next load: 15 us per call, measured)
+}
+template <typename T>
+__device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r, int tid) {
+  constexpr int TG = 16, RN = 6, SBW = TG * RN;
+  const int ti = tid & (TG - 1), tj = tid / TG, lane = tid & 63, wave = tid >> 6, nwaves = kThreads >> 6;
+  for (int I0 = 0; I0 < n; I0 += SBW) {
+    const int wi = n - I0 < SBW ? n - I0 : SBW;
+    for (int J0 = 0; J0 <= I0; J0 += SBW) {
+      const bool diag = J0 == I0;
+      const int wj = diag ? 0 : SBW, wc = wi + wj;          // (J0 < I0: a full block of columns)
+      int CR = w.region / (wc + 1);
+      if (CR > m_r) CR = m_r;
+      T* const rcs = w.Jc + (size_t)CR * wc;               // r of the staged rows
+      T acc[RN * RN];
 #pragma unroll
-  for (int bi = 0; bi < RN; ++bi)
+      for (int e = 0; e < RN * RN; ++e) acc[e] = (T)0;
+      for (int q0 = 0; q0 < m_r; q0 += CR) {
+        const int rows = m_r - q0 < CR ? m_r - q0 : CR;
+        if (row_major) {
+          for (int q = wave; q < rows; q += nwaves) {
+            const T* src = J + (size_t)(q0 + q) * J_ld;
+            for (int cx = lane; cx < wc; cx += 64) w.Jc[(size_t)q * wc + cx] = src[cx < wi ? I0 + cx : J0 + cx - wi];
+          }
+        } else {
+          for (int cx = wave; cx < wc; cx += nwaves) {
+            const T* src = J + (size_t)(cx < wi ? I0 + cx : J0 + cx - wi) * J_ld + q0;
+            for (int q = lane; q < rows; q += 64) w.Jc[(size_t)q * wc + cx] = src[q];
+          }
+        }
+        if (diag)
+          for (int idx = tid; idx < rows; idx += kThreads) rcs[idx] = r[q0 + idx];
+        __syncthreads();
+        if (tid < TG * TG) {
+          if (diag) jtj_superblock_rows<T, true>(w.Jc, wc, wi, wj, rows, ti, tj, acc);
+          else jtj_superblock_rows<T, false>(w.Jc, wc, wi, wj, rows, ti, tj, acc);
+        }
+        if (diag) {                                          // c = J^T r for the columns of this diagonal block; 0.5 |r|^2 once
+          for (int i = tid; i < wi; i += kThreads) {
+            T cacc = 0;
+            for (int q = 0; q < rows; ++q) cacc += w.Jc[(size_t)q * wc + i] * rcs[q];
+            w.cvec[I0 + i] += cacc;
+          }
+          if (I0 == 0 && tid == 0) {
+            T racc = 0;
+            for (int q = 0; q < rows; ++q) racc += rcs[q] * rcs[q];
+            w.red[8] += racc;
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < TG * TG) {
 #pragma unroll
-    for (int bj = 0; bj < RN; ++bj) {
-      const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
-      if ((!DIAG || bj <= bi) && i < n && j < n && j <= i) acc[bi * RN + bj] += w.H[i + (size_t)j * w.ldh];
+        for (int bi = 0; bi < RN; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < RN; ++bj) {
+            const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
+            if ((!diag || bj <= bi) && i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] = acc[bi * RN + bj];
+          }
+      }
     }
-#pragma unroll
-  for (int bi = 0; bi < RN; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < RN; ++bj) {
-      const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
-      if ((!DIAG || bj <= bi) && i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] = acc[bi * RN + bj];
-    }
+  }
 }
 // H.lower(n x n) += J^T J, cvec = J^T r, diag += lambda; returns 0.5|r|^2 in w.red[8]   (residual.hpp:206-225,
 // nonlinear.cc:182-189).  H must be zero in its n x n block and cvec is overwritten.
@@ -314,6 +366,15 @@ __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T
   for (int i = tid; i < n; i += kThreads) w.cvec[i] = (T)0;
   if (tid == 0) w.red[8] = (T)0;
   __syncthreads();
+  if constexpr (LARGE) {
+    accumulate_jtj_large<T>(w, n, m_r, J, J_ld, row_major, r, tid);
+    if (lambda > (T)0)
+      for (int i = tid; i < n; i += kThreads) w.H[i + (size_t)i * w.ldh] += lambda;
+    if (tid == 0) w.red[8] *= (T)0.5;
+    __threadfence_block();
+    __syncthreads();
+    return;
+  }
   const int CR = w.chunk_rows;
   for (int q0 = 0; q0 < m_r; q0 += CR) {
     const int rows = (m_r - q0 < CR) ? (m_r - q0) : CR;
@@ -332,14 +393,7 @@ __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T
     __syncthreads();
     // 2-D register tiling: thread (ti, tj) of a TG x TG grid accumulates G(i, j) for i = ti + TG bi, j = tj + TG bj, bi >= bj: per row of
     // J it reads RN + RN operands (broadcasts) for RN (RN + 1) / 2 FMAs, instead of five LDS reads for four FMAs
-    if constexpr (LARGE) {
-      for (int I0 = 0; I0 < n; I0 += 96) {
-        for (int J0 = 0; J0 < I0; J0 += 96) jtj_superblock<T, false>(w, n, rows, I0, J0, tid);
-        jtj_superblock<T, true>(w, n, rows, I0, I0, tid);
-      }
-    } else {
-      jtj_tile_rows_impl<T, TG, R>(w, n, rows, tid);   // n <= n + k <= TG R
-    }
+    jtj_tile_rows_impl<T, TG, R>(w, n, rows, tid);   // n <= n + k <= TG R
     for (int i = tid; i < n; i += kThreads) {
       T acc = 0;
       for (int q = 0; q < rows; ++q) acc += w.Jc[(size_t)q * n + i] * w.rc[q];
@@ -861,7 +915,7 @@ __device__ MO_INLINE void update_state(const Ws<T>& w, int n, int k, int m, T ap
 // R = ceil((n + k) / TG) blocks per thread and dimension (also the block count of the J^T J register tiling: n <= TG R).
 // LARGE: H in the workgroup's global workspace (a.H_work), blocked factorisation, 96-wide J^T J super-blocks: any n + k the LDS vectors allow.
 template <typename T, int MODE, int TG, int R, bool LARGE = false>
-__global__ __launch_bounds__(TG * TG) void kkt_generic_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ws<T> w;
   const int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
@@ -1152,6 +1206,7 @@ __global__ __launch_bounds__(kMaxThreads) void nullspace_kernel(const KernelArgs
   T* const pidx = lp; lp += k;  // column permutation (stored as T)
   T* const nrm = lp; lp += k;   // column norms
   w.chunk_rows = chunk_rows_for(n, m_r, (int)sizeof(T));
+  w.region = 0;
   w.Jc = lp; lp += (size_t)w.chunk_rows * n; w.rc = lp; lp += w.chunk_rows;
   w.red = lp; lp += 16;
   w.iflag = reinterpret_cast<int*>(lp);
