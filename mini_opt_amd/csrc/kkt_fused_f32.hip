@@ -168,6 +168,23 @@ template <int NT> __device__ inline void stv32(float* arr, int j, const float (&
   }
 }
 
+// the same on a caller's array of nn <= 16 NT entries (nn a multiple of 4: a lane's four variables are all inside or all outside)
+template <int NT> __device__ inline void stv32_n(float* arr, int j, int nn, const float (&v)[NT]) {
+#pragma unroll
+  for (int h = 0; h < NT / 4; ++h) {
+    f4 t; t[0] = v[4 * h]; t[1] = v[4 * h + 1]; t[2] = v[4 * h + 2]; t[3] = v[4 * h + 3];
+    if (64 * h + 4 * j < nn) *(f4*)(arr + 64 * h + 4 * j) = t;
+  }
+}
+template <int NT> __device__ inline void ldv32_n(const float* arr, int j, int nn, float (&v)[NT]) {
+#pragma unroll
+  for (int h = 0; h < NT / 4; ++h) {
+    f4 t = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (64 * h + 4 * j < nn) t = *(const f4*)(arr + 64 * h + 4 * j);
+    v[4 * h] = t[0]; v[4 * h + 1] = t[1]; v[4 * h + 2] = t[2]; v[4 * h + 3] = t[3];
+  }
+}
+
 template <int NT, int WPS> struct Cfg32 {
   static constexpr int N = 16 * NT;
   static constexpr int NH = NT / 4;                // 16-byte J pieces per lane per 4-row group
@@ -178,7 +195,9 @@ template <int NT, int WPS> struct Cfg32 {
   static constexpr int LDS = D * SLOT + VEC;
 };
 
-template <int NT, int WPS>
+// PAD: n is any multiple of 4 up to N = 16 NT and the system is padded to the grid inside the kernel (identity rows, zero right-hand side);
+// without it n == N is a compile-time fact and every mask below folds away (BASELINE configs[3] runs that instantiation).
+template <int NT, int WPS, bool PAD>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const KernelArgs a) {
   using C = Cfg32<NT, WPS>;
   constexpr int N = C::N, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
@@ -208,6 +227,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
   const int m_lay = a.m;
   const bool no_ineq = (a.flags & MO_STEP_NO_INEQUALITIES) != 0;
   const int k = a.k, m = no_ineq ? 0 : a.m, m_r = a.m_r;
+  const int nn = PAD ? a.n : N;   // variables (PAD: a multiple of 4, N - 63 .. N)
   const int nsteps = m_r >> 2;
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
@@ -224,6 +244,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  if (PAD && nn < N) {  // the lanes beyond a row of J never write their ring bytes: zeros there, once
+    for (int i = lane_id32() * 16; i < D * SLOT; i += 64 * 16) *(f4*)(smem + i) = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    lds_fence32();
+  }
   if (a.stagger > 0) {  // start stagger between the waves that share a SIMD (see kkt_fused.hip): equal-cost problems keep waves in lockstep
     const int slot = wave >> 2;
     for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
@@ -248,16 +272,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     const int g = lane >> 4, j = lane & 15;
 
     // ---- J stream set-up: lane (g, j) of 4-row group s fetches J(4s + g, 64h + 4j .. +3), h < NH; lane 0 fetches r[4s .. 4s+3]
-    const char* jsrc = reinterpret_cast<const char*>((const float*)a.J + p * a.J_stride + (size_t)g * N + 4 * j);
+    const char* jsrc = reinterpret_cast<const char*>((const float*)a.J + p * a.J_stride + (size_t)g * nn + 4 * j);
     const char* rsrc = reinterpret_cast<const char*>((const float*)a.r + p * a.r_stride);
     const char* const lane_piece = smem + lane * 16;
     const char* const r_elem = smem + NH * 1024 + 4 * g;
     auto issue = [&](int slot) {
       const unsigned dst = ring_base + slot * SLOT;
 #pragma unroll
-      for (int h = 0; h < NH; ++h) dma16_f32(jsrc + 256 * h, dst + h * 1024);
-      if (lane < 1) dma16_f32(rsrc, dst + NH * 1024);
-      jsrc += 4 * N * 4;
+      for (int h = 0; h < NH; ++h)
+        if (!PAD || 64 * h + 4 * j < nn) dma16_f32(jsrc + 256 * h, dst + h * 1024);   // (lane 0 of every piece is inside the row: the grid is the smallest that holds nn)
+      if (lane < 4) dma4_f32(rsrc + 4 * lane, dst + NH * 1024);   // r[4s .. 4s+3] as four dwords: no alignment asked of r
+      jsrc += 4 * nn * 4;
       rsrc += 16;
     };
 #pragma unroll
@@ -270,17 +295,18 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     f4 U[NB * NB];
 #pragma unroll
     for (int q = 0; q < NB * NB; ++q) U[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    dma_words(vp, vec_base, N, lane);
+    dma_words(vp, vec_base, nn, lane);
+    for (int i = nn + lane; i < N; i += 64) xs[i] = 0.0f;
     if (m > 0) {
       const long long coff = p * ka->cons_stride;
       dma_words(ka->cons_var + coff, vec_base + (3 * N + 256) * 4, m, lane);
       dma_words((const float*)ka->cons_a + coff, vec_base + (3 * N) * 4, m, lane);
       dma_words((const float*)ka->cons_b + coff, vec_base + (3 * N + 64) * 4, m, lane);
-      dma_words(vp + N, vec_base + (3 * N + 128) * 4, m, lane);
-      dma_words(vp + N + m + k, vec_base + (3 * N + 192) * 4, m, lane);
+      dma_words(vp + nn, vec_base + (3 * N + 128) * 4, m, lane);
+      dma_words(vp + nn + m + k, vec_base + (3 * N + 192) * 4, m, lane);
     }
     if (k > 0) {
-      dma_words(vp + N + m_lay, vec_base + (3 * N + 320) * 4, k, lane);
+      dma_words(vp + nn + m_lay, vec_base + (3 * N + 320) * 4, k, lane);
       dma_words((const float*)ka->b + p * ka->b_stride, vec_base + (3 * N + 336) * 4, k, lane);
     }
 
@@ -317,6 +343,30 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
         }
       }
     }
+    if (m_r & 3) {  // wave-uniform: up to three rows behind the last whole group -- plain loads, the lanes of the missing rows feed zeros
+      float ops[NT];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) ops[c] = 0.0f;
+      float rq = 0.0f;
+      if (g < (m_r & 3)) {
+        const float* row = (const float*)a.J + p * a.J_stride + (size_t)(4 * nsteps + g) * nn + 4 * j;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          if (!PAD || 64 * h + 4 * j < nn) {
+            const f4 v = *(const f4*)(row + 64 * h);
+            ops[4 * h] = v[0]; ops[4 * h + 1] = v[1]; ops[4 * h + 2] = v[2]; ops[4 * h + 3] = v[3];
+          }
+        }
+        rq = ((const float*)a.r + p * a.r_stride)[4 * nsteps + g];
+      }
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta) {
+        cpart[ta] = fmaf(ops[ta], rq, cpart[ta]);
+#pragma unroll
+        for (int tb = ta; tb < NT; ++tb)
+          U[ta * NB + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+      }
+    }
     float cvec[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum_f32(cpart[c]);
@@ -329,14 +379,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     int cvar = 0; float ca = 1.0f, cb = 0.0f, cs = 1.0f, cz = 0.0f;
     if (lane < m) { cvar = cV[lane]; ca = cA[lane]; cb = cB[lane]; cs = cS[lane]; cz = cZ[lane]; }
     lds_fence32();
-    bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= N));
+    bool bad_index = (lane < m) && ((cvar < 0) || (cvar >= nn));
     if (bad_index) cvar = 0;
     const bool slack_bad = __any((lane < m) && !(cs > 0.0f));
     bool any_bad_index = __any(bad_index);
     if (no_ineq && m_lay > 0) {  // the index check of Setup (qp.cc:70-72) does not depend on the flag
       bool bad = false;
       const int* cvp = ka->cons_var + p * ka->cons_stride;
-      for (int ix = lane; ix < m_lay; ix += 64) { const int v = cvp[ix]; bad = bad || v < 0 || v >= N; }
+      for (int ix = lane; ix < m_lay; ix += 64) { const int v = cvp[ix]; bad = bad || v < 0 || v >= nn; }
       any_bad_index = __any(bad);
     }
     const float cs_inv = rcp_f32(cs);
@@ -365,9 +415,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       for (int c = 0; c < NT; ++c) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          U[c * NB + c][t] += (j == 4 * g + t) ? (lam + dS[c]) : 0.0f;
           const int natcol = 64 * (c >> 2) + 16 * g + 4 * t + (c & 3);  // variable at position 16c + 4g + t
-          U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)natcol * A_ld] : 0.0f;
+          U[c * NB + c][t] += (j == 4 * g + t) ? ((!PAD || natcol < nn) ? lam + dS[c] : 1.0f) : 0.0f;   // padding: identity rows, zero right-hand side
+          U[c * NB + NT][t] = (j < k && (!PAD || natcol < nn)) ? Ap[j + (size_t)natcol * A_ld] : 0.0f;
           const float rv = rp[16 * c + 4 * g + t];
           U[c * NB + NR][t] = (j == 0) ? rv : 0.0f;
         }
@@ -454,15 +504,21 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       float outv[NT];
 #pragma unroll
       for (int c = 0; c < NT; ++c) outv[c] = st == MO_STATUS_OK ? dxv[c] : nanv;
-      stv32<NT>(dp, j, outv);
-      if (j < k) dp[N + m_lay + j] = st == MO_STATUS_OK ? dyv : nanv;
+      if (((uintptr_t)dp & 15) == 0) {   // (wave-uniform) whole 16-byte pieces where the caller's stride allows them
+        if (PAD) stv32_n<NT>(dp, j, nn, outv); else stv32<NT>(dp, j, outv);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+          if (!PAD || 64 * (c >> 2) + 4 * j < nn) dp[64 * (c >> 2) + 4 * j + (c & 3)] = outv[c];
+      }
+      if (j < k) dp[nn + m_lay + j] = st == MO_STATUS_OK ? dyv : nanv;
     }
     if (no_ineq) {  // ds = dz = 0 (qp.cc:366-386 writes only dx, dy)
-      for (int ix = lane; ix < m_lay; ix += 64) { dp[N + ix] = st == MO_STATUS_OK ? 0.0f : nanv; dp[N + m_lay + k + ix] = st == MO_STATUS_OK ? 0.0f : nanv; }
+      for (int ix = lane; ix < m_lay; ix += 64) { dp[nn + ix] = st == MO_STATUS_OK ? 0.0f : nanv; dp[nn + m_lay + k + ix] = st == MO_STATUS_OK ? 0.0f : nanv; }
     }
     if (lane < m) {
-      dp[N + lane] = st == MO_STATUS_OK ? dsv : nanv;
-      dp[N + m + k + lane] = st == MO_STATUS_OK ? dzv : nanv;
+      dp[nn + lane] = st == MO_STATUS_OK ? dsv : nanv;
+      dp[nn + m + k + lane] = st == MO_STATUS_OK ? dzv : nanv;
     }
     if (lane == 0) {
       if (ka->alpha) {
@@ -560,7 +616,7 @@ __device__ inline void solve_second_rhs_f32(const f4 (&U)[(NT + 2) * (NT + 2)], 
   }
 }
 
-template <int NT, int WPS>
+template <int NT, int WPS, bool PAD>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(const KernelArgs a) {
   using C = SolveCfg32<NT>;
   constexpr int N = C::N, NH = C::NH, DPS = C::DPS, SLOT = C::SLOT, D = C::D;
@@ -611,7 +667,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     // the argument block and the shape are re-read from the kernarg segment where they are used (see kkt_fused_solve_kernel): held in SGPRs
     // for the whole kernel they were spilled into VGPR lanes (226 v_writelane / 534 v_readlane in round 2's build)
     KArgs32 ka = fresh_args32();
-    const int k = ka->k, m = ka->m;
+    const int k = ka->k, m = ka->m, nn = PAD ? ka->n : N;   // nn variables (PAD: a multiple of 4) on the N = 16 NT grid
     const bool last_of_chunk = p + 1 >= chunk_end;
     int next_chunk = 0;
     unsigned long long next_ticket = 0;
@@ -649,11 +705,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     const bool iterate_mode = ka->mode == MODE_ITERATE || residual_mode;
     if (iterate_mode || ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
 #pragma unroll
-      for (int c = 0; c < NT; ++c) xv[c] = vp[natvar32(c, j)];
-      if (j < k) yv = vp[N + m + j];
-      if (lane < m) { cs = vp[N + lane]; cz = vp[N + m + k + lane]; }
+      for (int c = 0; c < NT; ++c) xv[c] = (!PAD || natvar32(c, j) < nn) ? vp[natvar32(c, j)] : 0.0f;
+      if (j < k) yv = vp[nn + m + j];
+      if (lane < m) { cs = vp[nn + lane]; cz = vp[nn + m + k + lane]; }
     }
-    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= N)));
+    const bool bad_index = __any((lane < m) && ((cvar < 0) || (cvar >= nn)));
     if (bad_index) cvar = 0;
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
@@ -717,20 +773,29 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       const bool include_ineq = !guess_pass && !(residual_mode && (ka->flags & MO_STEP_NO_INEQUALITIES));
       const int lane = lane_id32(), g = lane >> 4, j = lane & 15;  // re-made opaque every pass (nothing lane-derived is kept across the factorisation)
       ka = fresh_args32();
-      const int k = ka->k, m = ka->m;
+      const int k = ka->k, m = ka->m, nn = PAD ? ka->n : N;
       // ---------------------------------------------------------------- part A: tiles, residual, norms
       const bool stream_now = !qpl && __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;
-      const char* jsrc = reinterpret_cast<const char*>((const float*)ka->J + p * ka->J_stride + (size_t)g * N + 4 * j);
+      const char* jsrc = reinterpret_cast<const char*>((const float*)ka->J + p * ka->J_stride + (size_t)g * nn + 4 * j);
       const char* rsrc = reinterpret_cast<const char*>((const float*)ka->r + p * ka->r_stride);
       auto issue = [&](int slot) {
         const unsigned dst = ring_base + slot * SLOT;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) dma16_f32(jsrc + 256 * h, dst + h * 1024);
-        if (lane < 1) dma16_f32(rsrc, dst + NH * 1024);
-        jsrc += 4 * N * 4;
+        for (int h = 0; h < NH; ++h)
+          if (!PAD || 64 * h + 4 * j < nn) dma16_f32(jsrc + 256 * h, dst + h * 1024);   // (lane 0 of every piece is inside the row)
+        if (lane < 4) dma4_f32(rsrc + 4 * lane, dst + NH * 1024);   // r[4s .. 4s+3] as four dwords: no alignment asked of r
+        jsrc += 4 * nn * 4;
         rsrc += 16;
       };
       if (stream_now) {
+        if (PAD && nn < N) {  // the pieces beyond the row are never written by the DMAs, and the ring held the previous problem's parked tiles: zeros there
+#pragma unroll
+          for (int u = 0; u < D; ++u)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+              if (PAD && 64 * h + 4 * j >= nn) *(f4*)(smem + lane * 16 + u * SLOT + h * 1024) = f4{0.0f, 0.0f, 0.0f, 0.0f};
+          lds_fence32();
+        }
 #pragma unroll
         for (int u = 0; u < D; ++u)
           if (u < nsteps) issue(u);
@@ -757,12 +822,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
             for (int t = 0; t < 4; ++t) {
               const int vr = natvar32(ta, 4 * g + t), vc = natvar32(tb, j);
               const int hi = vr > vc ? vr : vc, lo = vr > vc ? vc : vr;
-              U[ta * NB + tb][t] = Gp[hi + (size_t)lo * ka->G_ld];
+              U[ta * NB + tb][t] = (!PAD || hi < nn) ? Gp[hi + (size_t)lo * ka->G_ld] : 0.0f;
             }
           }
         }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) cvec[c] = cp[natvar32(c, j)];
+        for (int c = 0; c < NT; ++c) cvec[c] = (!PAD || natvar32(c, j) < nn) ? cp[natvar32(c, j)] : 0.0f;
       } else if (stream_now) {
         const char* const lane_piece = smem + lane * 16;
         const char* const r_elem = smem + NH * 1024 + 4 * g;
@@ -799,6 +864,30 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
           }
         }
         wait_vmcnt32<0>();
+        if (m_r & 3) {  // wave-uniform: up to three rows behind the last whole group -- plain loads, the lanes of the missing rows feed zeros
+          float ops[NT];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) ops[c] = 0.0f;
+          float rq = 0.0f;
+          if (g < (m_r & 3)) {
+            const float* row = (const float*)ka->J + p * ka->J_stride + (size_t)(4 * nsteps + g) * nn + 4 * j;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+              if (!PAD || 64 * h + 4 * j < nn) {
+                const f4 v = *(const f4*)(row + 64 * h);
+                ops[4 * h] = v[0]; ops[4 * h + 1] = v[1]; ops[4 * h + 2] = v[2]; ops[4 * h + 3] = v[3];
+              }
+            }
+            rq = ((const float*)ka->r + p * ka->r_stride)[4 * nsteps + g];
+          }
+#pragma unroll
+          for (int ta = 0; ta < NT; ++ta) {
+            cpart[ta] = fmaf(ops[ta], rq, cpart[ta]);
+#pragma unroll
+            for (int tb = ta; tb < NT; ++tb)
+              U[ta * NB + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ops[ta], ops[tb], U[ta * NB + tb], 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int c = 0; c < NT; ++c) {  // G = J^T J + lambda I (nonlinear.cc:187-189): lambda is part of G in the residual too
 #pragma unroll
@@ -831,7 +920,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
 #pragma unroll
       for (int c = 0; c < NT; ++c) {  // [A_eq^T] tile column
 #pragma unroll
-        for (int t = 0; t < 4; ++t) U[c * NB + NT][t] = (j < k) ? Ap[j + (size_t)natvar32(c, 4 * g + t) * ka->A_ld] : 0.0f;
+        for (int t = 0; t < 4; ++t) U[c * NB + NT][t] = (j < k && (!PAD || natvar32(c, 4 * g + t) < nn)) ? Ap[j + (size_t)natvar32(c, 4 * g + t) * ka->A_ld] : 0.0f;
       }
       lds_fence32();
       float r_pi = 0.0f, r_comp = 0.0f;
@@ -886,10 +975,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
         float* ro = (float*)ka->r_out + p * ka->r_out_stride;
         if (g == 0) {
 #pragma unroll
-          for (int c = 0; c < NT; ++c) ro[natvar32(c, j)] = r_d[c];
-          if (j < k) ro[N + m + j] = r_pe;
+          for (int c = 0; c < NT; ++c)
+            if (!PAD || natvar32(c, j) < nn) ro[natvar32(c, j)] = r_d[c];
+          if (j < k) ro[nn + m + j] = r_pe;
         }
-        if (lane < m) { ro[N + lane] = r_comp; ro[N + m + k + lane] = r_pi; }
+        if (lane < m) { ro[nn + lane] = r_comp; ro[nn + m + k + lane] = r_pi; }
         if (ka->kkt_out) {
           float kq[4];
           kkt_errors_sq(mu, kq);
@@ -959,7 +1049,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == 4 * g + t) ? dd[c] : 0.0f;
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == 4 * g + t) ? ((!PAD || natvar32(c, j) < nn) ? dd[c] : 1.0f) : 0.0f;   // padding: identity rows (their right-hand side is zero)
           if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[c]);          // -r_aug, position order (qp.cc:337-342)
         }
       }
@@ -1092,9 +1182,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
         if (ka->delta) {
           float* dp = (float*)ka->delta + p * ka->delta_stride;
-          for (int i = lane; i < N; i += 64) dp[i] = tmp[i];  // dx, natural order
-          if (lane < m) { dp[N + lane] = dsv; dp[N + m + k + lane] = dzv; }
-          if (g == 0 && j < k) dp[N + m + j] = dyv;
+          for (int i = lane; i < nn; i += 64) dp[i] = tmp[i];  // dx, natural order
+          if (lane < m) { dp[nn + lane] = dsv; dp[nn + m + k + lane] = dzv; }
+          if (g == 0 && j < k) dp[nn + m + j] = dyv;
         }
         if (ka->ip_out && lane == 0) {
           float* ip = (float*)ka->ip_out + p * MO_IP_RECORD;
@@ -1109,10 +1199,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     if (!residual_mode) {
       if (g == 0) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) vp[natvar32(c, j)] = xv[c];
-        if (j < k) vp[N + m + j] = yv;
+        for (int c = 0; c < NT; ++c)
+          if (!PAD || natvar32(c, j) < nn) vp[natvar32(c, j)] = xv[c];
+        if (j < k) vp[nn + m + j] = yv;
       }
-      if (lane < m) { vp[N + lane] = cs; vp[N + m + k + lane] = cz; }
+      if (lane < m) { vp[nn + lane] = cs; vp[nn + m + k + lane] = cz; }
     }
     const float ymin = row_min_f32((j < k) ? yv : INFINITY), yabs = -row_min_f32((j < k) ? -fabsf(yv) : INFINITY);
     if (lane == 0) {
@@ -1320,7 +1411,8 @@ bool aligned16_f32(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool fused_f32_supported(const KernelArgs& a, int dtype) {
   if (dtype != MO_F32) return false;
-  if (a.n != 128 && a.n != 64) return false;
+  if (a.mode == MODE_LINEARIZE && a.n != 128 && a.n != 64) return false;
+  if (a.n < 4 || a.n > 128 || (a.n & 3)) return false;   // step / Solve / Iterate / residual: any multiple of 4, padded inside the kernels to the 64 / 128 grid
   if (a.mode == MODE_LINEARIZE) {  // kkt_fused_f32_linearize_kernel: packed row-major J, rows in whole 4-row groups
     return a.J && a.ticket && a.G_out && a.c_out && a.J_row_major && a.J_ld == a.n && a.m_r > 0 && !(a.m_r & 3) && aligned16_f32(a.J) &&
            !(a.J_stride & 3) && aligned16_f32(a.r) && !(a.r_stride & 3) && a.G_out_ld >= a.n;
@@ -1330,8 +1422,8 @@ bool fused_f32_supported(const KernelArgs& a, int dtype) {
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {  // kkt_fused_f32_solve_kernel
     if (a.mode == MODE_RESIDUAL ? ((a.flags & ~MO_STEP_NO_INEQUALITIES) != 0 || !a.r_out) : a.flags != 0) return false;
     if (a.J) {
-      if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
-      if (!aligned16_f32(a.J) || (a.J_stride & 3) || !aligned16_f32(a.r) || (a.r_stride & 3)) return false;
+      if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0) return false;
+      if (!aligned16_f32(a.J) || (a.J_stride & 3)) return false;
     } else if (!a.G || !a.c || a.G_ld < a.n) {
       return false;
     }
@@ -1339,18 +1431,16 @@ bool fused_f32_supported(const KernelArgs& a, int dtype) {
   }
   if ((a.flags & ~MO_STEP_NO_INEQUALITIES) != 0 || a.mode != MODE_STEP) return false;
   if (!a.delta || !a.J) return false;
-  if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0 || (a.m_r & 3)) return false;
+  if (!a.J_row_major || a.J_ld != a.n || a.m_r <= 0) return false;
   if (!aligned16_f32(a.J) || (a.J_stride & 3)) return false;
-  if (!aligned16_f32(a.r) || (a.r_stride & 3)) return false;
-  if (!aligned16_f32(a.delta) || (a.delta_stride & 3)) return false;
   return true;
 }
 
 const char* fused_f32_name(const KernelArgs& a) {
-  if (a.mode == MODE_LINEARIZE) return a.n == 128 ? "fused_linearize_f32_n128" : "fused_linearize_f32_n64";
-  if (a.mode == MODE_STEP) return a.n == 128 ? "fused_mfma_f32_n128" : "fused_mfma_f32_n64";
-  if (!a.J) return a.n == 128 ? "fused_solve_qp_f32_n128" : "fused_solve_qp_f32_n64";
-  return a.n == 128 ? "fused_solve_mfma_f32_n128" : "fused_solve_mfma_f32_n64";
+  if (a.mode == MODE_LINEARIZE) return a.n > 64 ? "fused_linearize_f32_n128" : "fused_linearize_f32_n64";
+  if (a.mode == MODE_STEP) return a.n > 64 ? "fused_mfma_f32_n128" : "fused_mfma_f32_n64";
+  if (!a.J) return a.n > 64 ? "fused_solve_qp_f32_n128" : "fused_solve_qp_f32_n64";
+  return a.n > 64 ? "fused_solve_mfma_f32_n128" : "fused_solve_mfma_f32_n64";
 }
 
 hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t stream) {
@@ -1361,46 +1451,49 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   if (e != hipSuccess) return e;
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
   if (a.mode == MODE_LINEARIZE) {
-    const int wps = a.n == 128 ? 2 : 3;
+    const int wps = a.n > 64 ? 2 : 3;
     long long grid = num_cus;
     const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+    if (a.n > 64) hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<4, 3>), dim3((unsigned)grid), dim3(768), 0, stream, a);
     return hipGetLastError();
   }
   if (a.mode != MODE_STEP) {  // Solve / Iterate / KKT residual: one wave per SIMD at n = 128 (216 tile registers + the state), three at n = 64
-    const int wps = a.n == 128 ? 1 : 3;
+    const int wps = a.n > 64 ? 1 : 3;
     long long grid = num_cus;
     const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 3>), dim3((unsigned)grid), dim3(768), 0, stream, a);
+    if (a.n > 64) { if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1, false>), dim3((unsigned)grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1, true>), dim3((unsigned)grid), dim3(256), 0, stream, a); }
+    else { if (a.n == 64) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 3, false>), dim3((unsigned)grid), dim3(768), 0, stream, a); else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 3, true>), dim3((unsigned)grid), dim3(768), 0, stream, a); }
     return hipGetLastError();
   }
-  if (a.n == 128 && env_wps == 1) {
+  if (a.n > 64 && env_wps == 1) {
     constexpr int WPS = 1;
     long long grid = num_cus;
     const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
-  } else if (a.n == 128) {
+    if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, true>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+  } else if (a.n > 64) {
     constexpr int WPS = 2;  // 255 VGPRs, no scratch: the 216 accumulator registers + operands just fit two waves per SIMD
     long long grid = num_cus;
     const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+    if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, true>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
   } else {
     constexpr int WPS = 3;
     long long grid = num_cus;
     const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((kkt_fused_f32_kernel<4, WPS>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+    if (a.n == 64) hipLaunchKernelGGL((kkt_fused_f32_kernel<4, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f32_kernel<4, WPS, true>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
   }
   return hipGetLastError();
 }
