@@ -816,6 +816,23 @@ template <int NT, int PA, int IDX, int Q> __device__ inline void la_mfma(d4 (&U)
     }
   }
 }
+// Work items per pivot of block step PA: one on the 32 / 64 grids (at most 12 items for 16 pivots), up to three on the 96 / 128 grids.
+template <int NB> constexpr int la_per_pivot(int pa) { return (la_count<NB>(pa) + 15) / 16; }
+// What goes to wait point P (0 .. 3) of pivot K: with one item per pivot its P-th MFMA; with M > 1 the whole item K M + (its slot at P) --
+// items stay in order (all four MFMAs of an item before the next one: the updates of a panel need its finished -Z, the next panel product
+// overwrites it).
+template <int NT, int PA, int K, int P> __device__ inline void la_point(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ) {
+  constexpr int M = la_per_pivot<NT + 1>(PA);
+  if constexpr (M <= 1) {
+    la_mfma<NT, PA, K, P>(U, negZ);
+  } else {
+    constexpr int slot = M == 2 ? (P == 0 ? 0 : (P == 2 ? 1 : -1)) : (P < M ? P : -1);
+    if constexpr (slot >= 0) {
+      la_mfma<NT, PA, K * M + slot, 0>(U, negZ); la_mfma<NT, PA, K * M + slot, 1>(U, negZ);
+      la_mfma<NT, PA, K * M + slot, 2>(U, negZ); la_mfma<NT, PA, K * M + slot, 3>(U, negZ);
+    }
+  }
+}
 // sweep_step_lean with the four MFMAs of one work item placed at the points where its dependent chain waits (in-order issue: an MFMA
 // behind the whole step would wait with it): behind the reciprocal's issue, behind the row broadcast's LDS request, behind the column
 // broadcasts, behind the rank-1 update.
@@ -827,7 +844,7 @@ __device__ inline void sweep_step_work(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ, d
   constexpr unsigned long long mrow = 0xFFFFull << (16 * src_g);
   d4& T = U[(PA + 1) * NB + (PA + 1)];
   if (!active) {  // wave-uniform: pivots beyond the y tile's k rows -- only the work
-    la_mfma<NT, PA, K, 0>(U, negZ); la_mfma<NT, PA, K, 1>(U, negZ); la_mfma<NT, PA, K, 2>(U, negZ); la_mfma<NT, PA, K, 3>(U, negZ);
+    la_point<NT, PA, K, 0>(U, negZ); la_point<NT, PA, K, 1>(U, negZ); la_point<NT, PA, K, 2>(U, negZ); la_point<NT, PA, K, 3>(U, negZ);
     return;
   }
   const double rowreg = T[src_t];
@@ -835,7 +852,7 @@ __device__ inline void sweep_step_work(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ, d
   double inv = __builtin_amdgcn_rcp(d);
   const double rowk = bpermute_f64((16 * src_g + j) * 4, rowreg);
   __builtin_amdgcn_sched_barrier(0);
-  la_mfma<NT, PA, K, 0>(U, negZ);                       // covers v_rcp_f64 and the LDS round trip of the row broadcast
+  la_point<NT, PA, K, 0>(U, negZ);                       // covers v_rcp_f64 and the LDS round trip of the row broadcast
   __builtin_amdgcn_sched_barrier(0);
   inv = fma(inv, fma(-d, inv, 1.0), inv);
   asm volatile("v_fma_f64 %0, %1, 0, %0" : "+v"(bad) : "v"(inv));
@@ -843,13 +860,13 @@ __device__ inline void sweep_step_work(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ, d
 #pragma unroll
   for (int t = 0; t < 4; ++t) f[t] = row_bcast64<K>(T[t]);
   __builtin_amdgcn_sched_barrier(0);
-  la_mfma<NT, PA, K, 1>(U, negZ);
+  la_point<NT, PA, K, 1>(U, negZ);
   __builtin_amdgcn_sched_barrier(0);
   double rk = rowk * inv;
   masked_set_neg<mcol>(rk, inv);
   masked_zero4<mcol>(T);
   __builtin_amdgcn_sched_barrier(0);
-  la_mfma<NT, PA, K, 2>(U, negZ);
+  la_point<NT, PA, K, 2>(U, negZ);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < 4; ++t) T[t] = fma(-f[t], rk, T[t]);
@@ -857,7 +874,7 @@ __device__ inline void sweep_step_work(d4 (&U)[(NT + 1) * (NT + 1)], d4& negZ, d
   masked_set<mrow>(rowk_new, rk);
   T[src_t] = rowk_new;
   __builtin_amdgcn_sched_barrier(0);
-  la_mfma<NT, PA, K, 3>(U, negZ);
+  la_point<NT, PA, K, 3>(U, negZ);
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int NT, int PA, int K> struct SweepWithWork {
@@ -868,7 +885,7 @@ template <int NT, int PA, int K> struct SweepWithWork {
 };
 template <int NT, int PA> struct SweepWithWork<NT, PA, 16> {
   static __device__ inline void run(d4 (&)[(NT + 1) * (NT + 1)], d4&, double&, int, int, int) {
-    static_assert(la_count<NT + 1>(PA) <= 16, "one work item per pivot");
+    static_assert(la_count<NT + 1>(PA) <= 16 * la_per_pivot<NT + 1>(PA) && la_per_pivot<NT + 1>(PA) <= 4, "work items per pivot");
   }
 };
 template <int NT, int PA> struct LookAheadSteps {
@@ -1239,7 +1256,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     // whatever is left): +0.4 % on two boxes; priority on the J stream instead: -0.8 %.
     if (a.chain_prio) __builtin_amdgcn_s_setprio(1);
     bool ok = true;
-    if constexpr (SW == 6) {
+#ifndef MO_NO_LOOKAHEAD_128
+    constexpr bool kLookAhead = SW == 6 || (NT == 8 && NY == 1);   // the 128 grid runs one wave per SIMD: nothing else hides the sweeps there
+#else
+    constexpr bool kLookAhead = SW == 6;
+#endif
+    if constexpr (kLookAhead) {
       ok = block_eliminate_lookahead<NT>(U, k, g, j);
     } else {
 #pragma unroll
@@ -2013,7 +2035,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // the look-ahead elimination (bit-identical results) on the 64 grid: no gain in the step kernel at three waves per SIMD (DESIGN.md
       // section 8), but the Solve kernel runs two and its cached passes are chains: 9.38 -> 9.55 M solves/s, 11.86 -> 12.03 M predictor-corrector
       bool elim_ok;
+#ifndef MO_NO_LOOKAHEAD_128
+      if constexpr (NY == 1 && (NT == 4 || NT == 8)) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
+#else
       if constexpr (NY == 1 && NT == 4) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
+#endif
       else elim_ok = block_eliminate<NT, SW, NY>(U, k, g, j);
       if (!elim_ok) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
 #else

@@ -1,5 +1,9 @@
 set -e
 mkdir -p gpurun_out
 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1
-python tools/bench_f32_offgrid.py > gpurun_out/f32_offgrid.log 2>&1
-python tools/bench_f32_offgrid.py 36 4 20 64 65536 >> gpurun_out/f32_offgrid.log 2>&1
+for i in 1 2; do
+python tools/bench_kernels.py --mode step --shape 128,14,64,256 --batch 16384 > gpurun_out/n128_step_la$i.log 2>&1
+MO_LIB_PATH=tools/ab_libs/libminiopt_nola128.so python tools/bench_kernels.py --mode step --shape 128,14,64,256 --batch 16384 > gpurun_out/n128_step_nola$i.log 2>&1
+done
+python tools/bench_kernels.py --mode solve --shape 128,14,64,256 --batch 16384 > gpurun_out/n128_solve_la.log 2>&1
+MO_LIB_PATH=tools/ab_libs/libminiopt_nola128.so python tools/bench_kernels.py --mode solve --shape 128,14,64,256 --batch 16384 > gpurun_out/n128_solve_nola.log 2>&1
