@@ -788,6 +788,9 @@ __device__ inline bool block_eliminate(d4 (&U)[(NT + NY) * (NT + NY)], int k, in
   return ok;
 }
 
+#ifndef MO_LA_MIN_NT
+#define MO_LA_MIN_NT 6   // smallest tile grid (NT = n / 16) whose step kernel eliminates with look-ahead (A/B knob; 99 = only where SW == 6 asks)
+#endif
 // ---- look-ahead elimination (SW == 6) ------------------------------------------------------------------------------------------
 // The diagonal sweeps are dependent VALU chains, the trailing updates independent MFMA chains; in program order "sweep, then all updates"
 // a wave alternates between a phase that can only wait on itself and a phase that only feeds the matrix pipe.  Here the update of block
@@ -1256,11 +1259,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     // whatever is left): +0.4 % on two boxes; priority on the J stream instead: -0.8 %.
     if (a.chain_prio) __builtin_amdgcn_s_setprio(1);
     bool ok = true;
-#ifndef MO_NO_LOOKAHEAD_128
-    constexpr bool kLookAhead = SW == 6 || (NT == 8 && NY == 1);   // the 128 grid runs one wave per SIMD: nothing else hides the sweeps there
-#else
-    constexpr bool kLookAhead = SW == 6;
-#endif
+    constexpr bool kLookAhead = SW == 6 || (NT >= MO_LA_MIN_NT && NY == 1);   // the large grids run one or two waves per SIMD: little else hides the sweeps there
     if constexpr (kLookAhead) {
       ok = block_eliminate_lookahead<NT>(U, k, g, j);
     } else {
@@ -2035,11 +2034,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       // the look-ahead elimination (bit-identical results) on the 64 grid: no gain in the step kernel at three waves per SIMD (DESIGN.md
       // section 8), but the Solve kernel runs two and its cached passes are chains: 9.38 -> 9.55 M solves/s, 11.86 -> 12.03 M predictor-corrector
       bool elim_ok;
-#ifndef MO_NO_LOOKAHEAD_128
-      if constexpr (NY == 1 && (NT == 4 || NT == 8)) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
-#else
-      if constexpr (NY == 1 && NT == 4) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
-#endif
+      if constexpr (NY == 1 && (NT == 4 || NT >= MO_LA_MIN_NT)) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
       else elim_ok = block_eliminate<NT, SW, NY>(U, k, g, j);
       if (!elim_ok) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
 #else
