@@ -188,6 +188,7 @@ def main():
         # code the GPU run executes
         dist = sharding.init_process_group(info, os.environ.get("MO_BENCH_BACKEND", "gloo"))
         dev = None
+        tgroup, tlabel, tdev = None, os.environ.get("MO_BENCH_BACKEND", "gloo") if info.world_size > 1 else "none", None
         kernel_name = "dry"
 
         def step():
@@ -203,10 +204,12 @@ def main():
         dev_index = info.local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev_index)
         dev = torch.device("cuda", dev_index)
-        # RCCL ("nccl" on ROCm) carries only the timing barrier and two scalar reductions; MO_BENCH_BACKEND=gloo rehearses the
-        # multi-rank path on a single-GPU box
-        backend = os.environ.get("MO_BENCH_BACKEND", "nccl")
-        dist = sharding.init_process_group(info, backend)
+        # RCCL ("nccl" on ROCm) carries only the timing barrier and two scalar reductions (the path has no data-path collective).  The
+        # default group is gloo -- a control plane that always works -- and the RCCL group on top of it is probed once: if any rank cannot
+        # form it, every rank times over gloo instead and the JSON line says so (`timing_sync`).  MO_BENCH_BACKEND=gloo skips RCCL
+        # altogether (rehearsals of the multi-rank path on a single-GPU box).
+        dist = sharding.init_process_group(info, "gloo")
+        tgroup, tlabel, tdev = sharding.timing_group(info, os.environ.get("MO_BENCH_BACKEND", "nccl"), dev)
         dtype = torch.float64 if cfg["dtype"] == "f64" else torch.float32
         prob, vars_, mu = synth.make_batch_torch(n, k, m, m_r, batch, dev, dtype, seed=synth.SEED + 1000 * info.rank)
         solver = Q.QPInteriorPointSolver(prob, force_generic=args.force_generic)
@@ -217,11 +220,17 @@ def main():
             return solver.NewtonStep(mu, 0.995)
         sync = torch.cuda.synchronize
 
+    def barrier():
+        if info.world_size > 1:
+            if tgroup is not None:
+                dist.barrier(group=tgroup, device_ids=[dev.index])
+            else:
+                dist.barrier()
+
     for _ in range(args.warmup):
         step()
     sync()
-    if info.world_size > 1:
-        dist.barrier()
+    barrier()
     sync()
     if not args.dry:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -236,12 +245,10 @@ def main():
             delta, alpha, status = step()
             e1.record()
     sync()
-    if info.world_size > 1:
-        dist.barrier()
+    barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    reduce_dev = dev if (not args.dry and os.environ.get("MO_BENCH_BACKEND", "nccl") == "nccl") else None
-    elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, reduce_dev)
+    elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, tdev, tgroup)
 
     out = None
     if info.rank == 0:
@@ -260,6 +267,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "name": config, "kernel": kernel_name, "batch_per_gpu": batch, "batch_total": total_batch,
                        "n": n, "k": k, "m": m, "m_r": m_r, "parallelism": f"batch-sharded x{info.world_size}, no collectives"},
+            "timing_sync": tlabel,   # what carried the barrier + MAX / SUM between the ranks ("none" at N = 1)
         }
     if args.dry:
         if info.rank == 0:

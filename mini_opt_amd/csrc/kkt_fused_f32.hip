@@ -17,6 +17,21 @@ namespace mo {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Phase stamps exist only in the diagnostic build of tools/phase_timer_f32.hip; the product kernel executes none.
+#ifdef MO_F32_STAMPS
+#define MO_STAMP32(i)                                                                                 \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t__;                                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                       \
+    stamp_acc[i] += t__ - stamp_prev;                                                                 \
+    stamp_prev = t__;                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define MO_STAMP32(i) do { } while (0)
+#endif
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 __device__ inline int lane_id32() {  // volatile on purpose: nothing derived from it is hoisted out of the problem loop
@@ -88,18 +103,28 @@ __device__ inline void dma_words(const void* src, unsigned lds_dst, int count, i
 template <int N> __device__ inline void wait_vmcnt32() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 __device__ inline void lds_fence32() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// EXEC-masked moves with immediate lane masks (see kkt_fused.hip for why the masks are immediates)
+// EXEC-masked moves with immediate lane masks (see kkt_fused.hip for why the masks are immediates, and for the pad: a DPP read of the VGPR
+// just written needs 2 wait states -- the s_mov_b64 that restores EXEC and `s_nop 0`; rounds 1-2 padded with `s_nop 4`, -DMO_F32_MASKED_PAD_4
+// restores that for A/B builds)
+#ifdef MO_F32_MASKED_PAD_4
+#define MO_F32_PAD "4"
+#else
+#define MO_F32_PAD "0"
+#endif
+#ifndef MO_F32_LOOKAHEAD
+#define MO_F32_LOOKAHEAD 0   // A/B knob: 1 = look-ahead elimination (measured: -2.2 % at BASELINE configs[3])
+#endif
 template <unsigned long long MASK> __device__ inline void masked_set_f32(float& dst, float src) {
   unsigned long long save;
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b32 %[d], %[s]\n\t"
-               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               "s_mov_b64 exec, %[sv]\n\ts_nop " MO_F32_PAD
                : [d] "+v"(dst), [sv] "=&s"(save)
                : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
 template <unsigned long long MASK> __device__ inline void masked_set_neg_f32(float& dst, float src) {
   unsigned long long save;
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_max_f32 %[d], -%[s], -%[s]\n\t"
-               "s_mov_b64 exec, %[sv]\n\ts_nop 4"
+               "s_mov_b64 exec, %[sv]\n\ts_nop " MO_F32_PAD
                : [d] "+v"(dst), [sv] "=&s"(save)
                : [s] "v"(src), [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
 }
@@ -107,7 +132,7 @@ template <unsigned long long MASK> __device__ inline void masked_zero4_f32(f4& T
   unsigned long long save;
   float t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3];
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b32 %[a], 0\n\tv_mov_b32 %[b], 0\n\t"
-               "v_mov_b32 %[c], 0\n\tv_mov_b32 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop 4"
+               "v_mov_b32 %[c], 0\n\tv_mov_b32 %[d], 0\n\ts_mov_b64 exec, %[sv]\n\ts_nop " MO_F32_PAD
                : [a] "+v"(t0), [b] "+v"(t1), [c] "+v"(t2), [d] "+v"(t3), [sv] "=&s"(save)
                : [lo] "i"((unsigned)(MASK & 0xffffffffull)), [hi] "i"((unsigned)(MASK >> 32)));
   T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
@@ -149,6 +174,127 @@ template <int KEND> struct SweepLoop32<KEND, KEND> {
 __device__ inline bool sweep_tile_f32(f4& T, int npiv, int j) {
   float bad = 0.0f;
   SweepLoop32<0, 16>::run(T, bad, npiv, j);
+  return bad == 0.0f;
+}
+
+// ---- look-ahead elimination of the step kernel ----------------------------------------------------------------------------------
+// Program order "sweep tile (pa, pa), then every update of block step pa" makes a wave alternate between a dependent VALU chain that
+// leaves the matrix pipe idle (16 pivots of ~150 cycles each) and a run of MFMAs that leaves the VALU idle -- and the fp32 MFMA, unlike
+// the fp64 one, does not share the VALU's datapath, so the two can run side by side inside ONE wave.  The update of block step pa is
+// split: the column of tile (pa+1, pa+1) first, then the sweep of that tile interleaved pivot by pivot with the remaining tile products
+// of step pa (they touch neither that tile nor its operands).  Work items (one item = one 16x16x16 tile product = four MFMAs) stay in
+// program order -- all four MFMAs of an item before the next one: the updates of a panel need its finished -Z, the next panel product
+// overwrites it -- so every tile sees the same operations in the same order as in the plain loop: bit-identical results.
+// Tile columns: x blocks 0 .. NT-1, y block NT, right-hand side NR = NT + 1 (NB = NT + 2); rows pb <= NT.
+template <int NT> constexpr int la32_rows(int pa, int pc) { return (pc < NT ? pc : NT) - pa; }   // tiles (pa+1 .. min(pc, NT), pc) updated at step pa
+template <int NT> constexpr int la32_count(int pa) { int c = 0; for (int pc = pa + 2; pc < NT + 2; ++pc) c += 1 + la32_rows<NT>(pa, pc); return c; }
+template <int NT> constexpr int la32_pc(int pa, int idx) {
+  for (int pc = pa + 2; pc < NT + 2; ++pc) { const int n = 1 + la32_rows<NT>(pa, pc); if (idx < n) return pc; idx -= n; }
+  return -1;
+}
+template <int NT> constexpr int la32_sub(int pa, int idx) {  // 0: the panel product -Z = (-T^-1) U_ac;  s >= 1: update of tile (pa + s, pc)
+  for (int pc = pa + 2; pc < NT + 2; ++pc) { const int n = 1 + la32_rows<NT>(pa, pc); if (idx < n) return idx; idx -= n; }
+  return -1;
+}
+template <int NT> constexpr int la32_per_pivot(int pa) { return (la32_count<NT>(pa) + 15) / 16; }
+// the Q-th of the four MFMAs of work item IDX of block step PA
+template <int NT, int PA, int IDX, int Q> __device__ inline void la32_mfma(f4 (&U)[(NT + 2) * (NT + 2)], f4& negZ) {
+  constexpr int NB = NT + 2;
+  if constexpr (IDX < la32_count<NT>(PA)) {
+    constexpr int pc = la32_pc<NT>(PA, IDX), sub = la32_sub<NT>(PA, IDX);
+    if constexpr (sub == 0) {
+      if constexpr (Q == 0) negZ = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      negZ = __builtin_amdgcn_mfma_f32_16x16x4f32(U[PA * NB + PA][Q], U[PA * NB + pc][Q], negZ, 0, 0, 0);
+    } else {
+      U[(PA + sub) * NB + pc] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[PA * NB + (PA + sub)][Q], negZ[Q], U[(PA + sub) * NB + pc], 0, 0, 0);
+    }
+  }
+}
+// What goes to wait point P (0 .. 3) of pivot K's chain: with one item per pivot its P-th MFMA; with M > 1 items per pivot (pivot K owns
+// items K M .. K M + M - 1) whole items, spread over the points in order.
+template <int NT, int PA, int K, int P> __device__ inline void la32_point(f4 (&U)[(NT + 2) * (NT + 2)], f4& negZ) {
+  constexpr int M = la32_per_pivot<NT>(PA);
+  static_assert(M <= 4, "work items per pivot");
+  if constexpr (M <= 1) {
+    la32_mfma<NT, PA, K, P>(U, negZ);
+  } else {
+    constexpr int slot = M == 2 ? (P == 0 ? 0 : (P == 2 ? 1 : -1)) : (P < M ? P : -1);
+    if constexpr (slot >= 0) {
+      la32_mfma<NT, PA, K * M + slot, 0>(U, negZ); la32_mfma<NT, PA, K * M + slot, 1>(U, negZ);
+      la32_mfma<NT, PA, K * M + slot, 2>(U, negZ); la32_mfma<NT, PA, K * M + slot, 3>(U, negZ);
+    }
+  }
+}
+template <int NT, int PA, int K>
+__device__ inline void sweep_step_work_f32(f4 (&U)[(NT + 2) * (NT + 2)], f4& negZ, float& bad, bool active, int j) {
+  constexpr int NB = NT + 2;
+  constexpr int src_g = K >> 2, src_t = K & 3;
+  constexpr unsigned long long mcol = 0x0001000100010001ull << K;
+  constexpr unsigned long long mrow = 0xFFFFull << (16 * src_g);
+  f4& T = U[(PA + 1) * NB + (PA + 1)];
+  if (!active) {  // wave-uniform: pivots beyond the y tile's k rows -- only the work
+    la32_point<NT, PA, K, 0>(U, negZ); la32_point<NT, PA, K, 1>(U, negZ); la32_point<NT, PA, K, 2>(U, negZ); la32_point<NT, PA, K, 3>(U, negZ);
+    return;
+  }
+  const float rowreg = T[src_t];
+  const float d = readlane_f32(rowreg, 16 * src_g + K);
+  float inv = __builtin_amdgcn_rcpf(d);
+  const float rowk = bpermute_f32((16 * src_g + j) * 4, rowreg);
+  __builtin_amdgcn_sched_barrier(0);
+  la32_point<NT, PA, K, 0>(U, negZ);                       // covers v_rcp_f32 and the LDS round trip of the row broadcast
+  __builtin_amdgcn_sched_barrier(0);
+  inv = fmaf(inv, fmaf(-d, inv, 1.0f), inv);
+  asm volatile("v_fma_f32 %0, %1, 0, %0" : "+v"(bad) : "v"(inv));
+  float f[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) f[t] = row_bcast_f32<K>(T[t]);
+  __builtin_amdgcn_sched_barrier(0);
+  la32_point<NT, PA, K, 1>(U, negZ);
+  __builtin_amdgcn_sched_barrier(0);
+  float rk = rowk * inv;
+  masked_set_neg_f32<mcol>(rk, inv);
+  masked_zero4_f32<mcol>(T);
+  __builtin_amdgcn_sched_barrier(0);
+  la32_point<NT, PA, K, 2>(U, negZ);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) T[t] = fmaf(-f[t], rk, T[t]);
+  float rowk_new = T[src_t];
+  masked_set_f32<mrow>(rowk_new, rk);
+  T[src_t] = rowk_new;
+  __builtin_amdgcn_sched_barrier(0);
+  la32_point<NT, PA, K, 3>(U, negZ);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int NT, int PA, int K> struct SweepWithWork32 {
+  static __device__ inline void run(f4 (&U)[(NT + 2) * (NT + 2)], f4& negZ, float& bad, int npiv, int j) {
+    sweep_step_work_f32<NT, PA, K>(U, negZ, bad, K < npiv, j);
+    SweepWithWork32<NT, PA, K + 1>::run(U, negZ, bad, npiv, j);
+  }
+};
+template <int NT, int PA> struct SweepWithWork32<NT, PA, 16> {
+  static __device__ inline void run(f4 (&)[(NT + 2) * (NT + 2)], f4&, float&, int, int) {
+    static_assert(la32_count<NT>(PA) <= 16 * la32_per_pivot<NT>(PA), "work items per pivot");
+  }
+};
+template <int NT, int PA> struct LookAheadSteps32 {
+  static __device__ inline void run(f4 (&U)[(NT + 2) * (NT + 2)], float& bad, int k, int j) {
+    constexpr int NB = NT + 2;
+    // the column of the next diagonal tile first
+    f4 negZ = mfma4_f32(U[PA * NB + PA], U[PA * NB + PA + 1], f4{0.0f, 0.0f, 0.0f, 0.0f});
+    U[(PA + 1) * NB + PA + 1] = mfma4_f32(U[PA * NB + PA + 1], negZ, U[(PA + 1) * NB + PA + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    SweepWithWork32<NT, PA, 0>::run(U, negZ, bad, PA + 1 < NT ? 16 : k, j);
+    if constexpr (PA + 1 < NT) LookAheadSteps32<NT, PA + 1>::run(U, bad, k, j);
+  }
+};
+// (block step NT -- the y tile -- has no update left: the back-substitution applies its swept tile itself)
+template <int NT>
+__device__ inline bool block_eliminate_lookahead_f32(f4 (&U)[(NT + 2) * (NT + 2)], int k, int j) {
+  float bad = 0.0f;
+  SweepLoop32<0, 16>::run(U[0], bad, 16, j);
+  __builtin_amdgcn_sched_barrier(0);
+  LookAheadSteps32<NT, 0>::run(U, bad, k, j);
   return bad == 0.0f;
 }
 
@@ -259,6 +405,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
   long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
+#ifdef MO_F32_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
 
   while (p < a.batch) {
     const bool last_of_chunk = p + 1 >= chunk_end;
@@ -310,6 +460,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       dma_words((const float*)ka->b + p * ka->b_stride, vec_base + (3 * N + 336) * 4, k, lane);
     }
 
+    MO_STAMP32(0);
     // ---- P1: G = J^T J on the matrix cores (upper block triangle), c = J^T r on the VALU
     float cpart[NT];
 #pragma unroll
@@ -371,6 +522,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
 #pragma unroll
     for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum_f32(cpart[c]);
 
+    MO_STAMP32(1);
     // ---- P3: barrier terms scattered per variable through LDS (duplicates on one variable accumulate)
     wait_vmcnt32<0>();
     ka = fresh_args32();
@@ -428,11 +580,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
 
     // ---- P5: block elimination with 16x16 pivot blocks (pivot blocks 0..NT; column NR only rides along)
     __builtin_amdgcn_sched_barrier(0);
+    MO_STAMP32(2);
     bool ok = true;
+#if MO_F32_LOOKAHEAD
+    ok = block_eliminate_lookahead_f32<NT>(U, k, j);
+#else
 #pragma unroll
     for (int pa = 0; pa <= NT; ++pa) {
       ok = sweep_tile_f32(U[pa * NB + pa], pa < NT ? 16 : k, j) && ok;
       __builtin_amdgcn_sched_barrier(0);
+      MO_STAMP32(3);
 #pragma unroll
       for (int pc = pa + 1; pc < NB; ++pc) {
         const f4 negZ = mfma4_f32(U[pa * NB + pa], U[pa * NB + pc], f4{0.0f, 0.0f, 0.0f, 0.0f});  // (-T^-1) U_ac
@@ -440,8 +597,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
         for (int pb = pa + 1; pb <= (pc < NT ? pc : NT); ++pb) U[pb * NB + pc] = mfma4_f32(U[pa * NB + pb], negZ, U[pb * NB + pc]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      MO_STAMP32(4);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
+    MO_STAMP32(4);
 
     // ---- P6: backward substitution; xb[c] = solution at permuted position 16c + j (replicated over g); xb[NT] = -y+
     float xb[NT + 1];
@@ -463,6 +623,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    MO_STAMP32(5);
     // ---- P7: direction, step lengths, status
     ka = fresh_args32();
     float dxv[NT];
@@ -528,6 +689,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       if (ka->status) ka->status[p] = st;
     }
     lds_fence32();  // the LDS vectors are re-initialised by the next problem
+    MO_STAMP32(6);
     if (last_of_chunk) {
       p = uniform64(next_ticket) + ticket_base;
       chunk_end = p + next_chunk;
@@ -535,6 +697,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
       ++p;
     }
   }
+#ifdef MO_F32_STAMPS
+  if ((threadIdx.x & 63) == 0 && a.debug) {
+    for (int i = 0; i < 8; ++i) atomicAdd(a.debug + i, stamp_acc[i]);
+    atomicAdd(a.debug + 8, 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -41,14 +41,45 @@ def init_process_group(info: RankInfo, backend: str):
     return dist
 
 
-def barrier_max_sum(info: RankInfo, elapsed_s: float, units: int, device=None) -> tuple[float, int]:
-    """Max of the per-rank wall time and sum of the per-rank unit counts (host-side scalars only)."""
+def timing_group(info: RankInfo, want: str, device=None, timeout_s: float = 120.0):
+    """The group that carries the timing barrier and the two scalar reductions: (group, label, device for the scalars).
+
+    The default process group (`init_process_group(info, "gloo")`) is the control plane and always works.  With `want == "nccl"` (RCCL on
+    ROCm -- the driver's one-rank-per-GPU runs) an RCCL group is created on top and probed with one all-reduce; every rank then reports over
+    gloo whether ITS probe worked, and RCCL is used only if it worked everywhere -- otherwise ALL ranks fall back to gloo together (no rank
+    is left waiting in a collective the others have given up on).  The path has no data-path collective, so which library carries the
+    barrier changes nothing that is measured; the label says which one it was."""
+    import torch.distributed as dist
+    if info.world_size == 1 or want != "nccl":
+        return None, want if info.world_size > 1 else "none", None
+    import datetime
+
+    import torch
+    ok, group, why = 1, None, ""
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe, group=group)
+        torch.cuda.synchronize(device)
+        if int(probe.item()) != info.world_size:
+            raise RuntimeError(f"probe all-reduce returned {probe.item()}")
+    except Exception as exc:  # RCCL unavailable here (e.g. two ranks sharing one GPU in a rehearsal, no IPC between the devices)
+        ok, why = 0, repr(exc)[:200]
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # over gloo: do all ranks have a working RCCL group?
+    if int(flag.item()) == 1:
+        return group, "rccl", device
+    return None, "gloo (rccl unavailable" + (": " + why if why else " on another rank") + ")", None
+
+
+def barrier_max_sum(info: RankInfo, elapsed_s: float, units: int, device=None, group=None) -> tuple[float, int]:
+    """Max of the per-rank wall time and sum of the per-rank unit counts (scalars only)."""
     if info.world_size == 1:
         return elapsed_s, units
     import torch
     import torch.distributed as dist
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     u = torch.tensor([units], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), int(u.item())

@@ -56,3 +56,21 @@ def test_bare_gpus_flag_runs_two_real_ranks():
     assert out["n_gpus"] == 2 and out["config"]["batch_total"] == 32768 and out["config"]["kernel"] == "fused_mfma_f64_n64"
     assert out["value"] > 1e6 and out["status_ok"] == out["status_total"]
     assert out["sustained"]["seconds"] >= 0.3 and out["sustained"]["value"] > 1e6
+
+
+def test_two_ranks_on_one_gpu_fall_back_from_rccl_to_gloo():
+    """Without MO_BENCH_BACKEND the ranks ask for RCCL.  Two ranks on ONE device cannot form an RCCL communicator: both must notice, agree over
+    the gloo control plane to time over gloo instead, and the run must still produce its line (a driver-run `--gpus N` never exits non-zero
+    because of the library that carries its barrier)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MO_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg5",
+           "--batch", "8192", "--no-cpu-baseline", "--sustain-seconds", "0"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["batch_total"] == 16384 and out["status_ok"] == out["status_total"]
+    assert out["timing_sync"] == "rccl" or out["timing_sync"].startswith("gloo (rccl unavailable"), out["timing_sync"]

@@ -70,6 +70,32 @@ def test_two_rank_sharded_step_matches_single_rank(tmp_path):
     assert agg[0] == 1.5 and agg[1] == total  # MAX of the per-rank times, SUM of the per-rank unit counts
 
 
+def _timing_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    info = sharding.RankInfo.from_env()
+    sharding.init_process_group(info, "gloo")
+    group, label, dev = sharding.timing_group(info, "nccl", device=None, timeout_s=30.0)   # no GPU here: RCCL cannot come up on any rank
+    dist.barrier(group=group)
+    t_max, units = sharding.barrier_max_sum(info, 1.0 + rank, 10 + rank, dev, group)
+    if rank == 0:
+        with open(os.path.join(out_dir, "timing.txt"), "w") as f:
+            f.write(f"{group is None}|{label}|{dev}|{t_max}|{units}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_timing_group_falls_back_to_gloo_on_every_rank_when_rccl_is_unavailable(tmp_path):
+    """bench.py asks for an RCCL group for its timing barrier; where RCCL cannot form one (here: no GPU at all) every rank must agree on gloo --
+    the fallback a driver-run `bench.py --gpus N` would take rather than exit non-zero -- and the reductions must still be right."""
+    world = 2
+    mp.spawn(_timing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    is_none, label, dev, t_max, units = open(tmp_path / "timing.txt").read().split("|")
+    assert is_none == "True" and dev == "None" and label.startswith("gloo (rccl unavailable")
+    assert float(t_max) == 2.0 and int(units) == 21
+    # one rank, or gloo asked for: no probe at all
+    assert sharding.timing_group(sharding.RankInfo(0, 0, 1), "nccl") == (None, "none", None)
+
+
 def test_synthetic_generator_rejects_shapes_it_cannot_build():
     """synth.make_batch_torch puts a lower and an upper bound on each of m / 2 DISTINCT variables: m must be even and <= 2 n.  The check
     runs on the host before any device op (an out-of-range gather on the device once faulted a GPU box); on a machine without a GPU it is
