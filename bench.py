@@ -70,6 +70,16 @@ def measured_traffic(kernel_name: str, config: str, batch: int):
             src["stale"] = True
             return None, src
         row = next(v for k, v in summ.items() if "kkt_fused" in k)
+        try:
+            # SIMD time per step from the same summary (the fp64 MFMA and the VALU are one datapath, their cycles add up):
+            # SQ_VALU_MFMA_BUSY_CYCLES (cycles) + SQ_ACTIVE_INST_VALU (quad-cycles) against duration x clock x 1 024 SIMDs
+            simd_cycles = float(row["counter_pass_kernel_ns"]) * float(row["effective_clock_ghz"]) * 1024.0 / batch
+            mfma = float(row["SQ_VALU_MFMA_BUSY_CYCLES"]) / batch
+            valu = (float(row["SQ_ACTIVE_INST_VALU"]) - float(row["SQ_INSTS_MFMA"])) * 4.0 / batch   # (the counter also holds 4 issue cycles per MFMA)
+            src["datapath"] = {"simd_cycles_per_step": simd_cycles, "mfma_busy_cycles_per_step": mfma, "other_valu_active_cycles_per_step": valu,
+                               "busy_frac": (mfma + valu) / simd_cycles, "clock_ghz": float(row["effective_clock_ghz"])}
+        except Exception:
+            pass
         return float(row["FETCH_SIZE"]) * 1024.0 * 2.0 + float(row["WRITE_SIZE"]) * 1024.0, src
     except Exception as exc:  # no summary for this workload (yet): traffic stays null
         src["error"] = repr(exc)
@@ -308,6 +318,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
                            "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes * batch,
+                           "datapath": traffic_src.pop("datapath", None),
                            "kernel_ms": kernel_ms, "scope": "rank 0's launches" if info.world_size > 1 else "the launch",
                            "fp64_tflops": flops * batch / (kernel_ms * 1e-3) / 1e12,
                            "fp64_frac_of_peak": flops * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int mode, int pr
 template <int KIND, int NACC, int GAP> int run(const char* name, float* d, long long* dc) {
   const int iters = 20000; long long h[8];
   for (int swap = 0; swap < 2; ++swap)
-    for (int prio = 0; prio < 1; ++prio)
+    for (int prio = 0; prio < 2; ++prio)
       for (int mode = 1; mode <= 3; mode += 2) {
         hipLaunchKernelGGL((k<KIND, NACC, GAP>), dim3(1), dim3(512), 0, 0, d, iters, mode, prio, swap, dc); CK(hipDeviceSynchronize());
         hipLaunchKernelGGL((k<KIND, NACC, GAP>), dim3(1), dim3(512), 0, 0, d, iters, mode, prio, swap, dc); CK(hipDeviceSynchronize());
@@ -73,6 +73,6 @@ int main() {
   float* d; long long* dc; CK(hipMalloc(&d, 4096)); CK(hipMalloc(&dc, 64));
   run<0, 8, 0>("indep v_fma_f32", d, dc); run<0, 8, 1>("indep v_fma_f32", d, dc); run<0, 8, 2>("indep v_fma_f32", d, dc); run<0, 8, 3>("indep v_fma_f32", d, dc);
   run<0, 8, 4>("indep v_fma_f32", d, dc); run<0, 8, 5>("indep v_fma_f32", d, dc); run<0, 8, 6>("indep v_fma_f32", d, dc);
-  run<1, 8, 2>("dependent v_fma_f32", d, dc); run<1, 8, 3>("dependent v_fma_f32", d, dc);
+  run<1, 8, 0>("dependent v_fma_f32", d, dc); run<1, 8, 2>("dependent v_fma_f32", d, dc); run<0, 1, 0>("indep v_fma_f32", d, dc); run<1, 1, 0>("dependent v_fma_f32", d, dc);
   return 0;
 }
