@@ -1071,11 +1071,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   // queue is long, single problems at the end) because one counter word sustains only ~88 M atomics/s, and the next
   // chunk is requested at the START of the current chunk's last problem, so the atomic's latency hides under the J stream.
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);  // ~ remaining / (4 waves' worth)
+  // Small launches -- at most a.static_rounds problems per wave -- are split STATICALLY, round by round, in slot-major wave order (first one wave on
+  // every SIMD of every CU, then the second wave of every SIMD, ...): no ticket at all.  A wave must otherwise wait for a ticket just to
+  // learn that nothing is left, and 3 072 waves asking one counter word at ~88 M atomics/s is 35 us -- as long as the whole first round of
+  // BASELINE configs[1] (4 096 problems).  A partial round then also lands one wave per SIMD instead of three per SIMD on a third of the CUs.
+  const long long waves_all = (long long)gridDim.x * WAVES;
+  const bool st_rounds = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * waves_all;   // wave-uniform
   auto chunk_for = [&](long long observed) -> int {
+    if (st_rounds) return 1;
     const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
-  auto take_ticket = [&](int chunk) -> unsigned long long {
+  auto take_ticket = [&](int chunk, long long p_now) -> unsigned long long {
+    if (st_rounds) return (unsigned long long)p_now;   // static rounds: the next problem of this wave is p_now + waves_all (= "ticket" p_now + ticket_base)
     unsigned long long t = 0;
     if (lane_id() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
@@ -1088,7 +1096,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   // through the phases in lockstep for the whole launch -- three J streams together, then three dependent pivot chains together.  Delaying
   // the second and third wave of each SIMD once, by about a third of a problem each (a.stagger units of 127 x 64 cycles), keeps one wave
   // in the matrix-bound phase while another is in the sweeps: +1.4 % at cfg 3 (A/B on one box), nothing at cfg 2.
-  if (a.stagger > 0) {
+  if (a.stagger > 0 && !st_rounds) {
     const int slot = wave >> 2;
     for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -1097,7 +1105,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
   // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
-  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
+  long long p = st_rounds ? (long long)(wave >> 2) * ((long long)gridDim.x * 4) + (long long)blockIdx.x * 4 + (wave & 3) : ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -1106,7 +1114,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f64_kernel(const Ker
     unsigned long long next_ticket = 0;
     if (last_of_chunk) {
       next_chunk = chunk_for(p);
-      next_ticket = take_ticket(next_chunk);
+      next_ticket = take_ticket(next_chunk, p);
     }
     // Lane coordinates are made opaque once per problem so that nothing derived from them (gather addresses, masks,
     // bpermute addresses) is hoisted out of the problem loop and kept live for the whole kernel: the tile registers
@@ -1400,11 +1408,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
   for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
   lds_fence();
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  // Small launches -- at most a.static_rounds problems per wave -- are split STATICALLY, round by round, in slot-major wave order (first one wave on
+  // every SIMD of every CU, then the second wave of every SIMD, ...): no ticket at all.  A wave must otherwise wait for a ticket just to
+  // learn that nothing is left, and 3 072 waves asking one counter word at ~88 M atomics/s is 35 us -- as long as the whole first round of
+  // BASELINE configs[1] (4 096 problems).  A partial round then also lands one wave per SIMD instead of three per SIMD on a third of the CUs.
+  const long long waves_all = (long long)gridDim.x * WAVES;
+  const bool st_rounds = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * waves_all;   // wave-uniform
   auto chunk_for = [&](long long observed) -> int {
+    if (st_rounds) return 1;
     const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
-  auto take_ticket = [&](int chunk) -> unsigned long long {
+  auto take_ticket = [&](int chunk, long long p_now) -> unsigned long long {
+    if (st_rounds) return (unsigned long long)p_now;   // static rounds: the next problem of this wave is p_now + waves_all (= "ticket" p_now + ticket_base)
     unsigned long long t = 0;
     if (lane_id() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
@@ -1418,13 +1434,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_linearize_kernel(con
   // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
-  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
+  long long p = st_rounds ? (long long)(wave >> 2) * ((long long)gridDim.x * 4) + (long long)blockIdx.x * 4 + (wave & 3) : ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
   while (p < a.batch) {
     const bool last_of_chunk = p + 1 >= chunk_end;
     int next_chunk = 0;
     unsigned long long next_ticket = 0;
-    if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk); }
+    if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk, p); }
     const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
     JStream<NT, D, JMODE> stream;
@@ -1580,11 +1596,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   lds_fence();
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);  // ~ remaining / (4 waves' worth)
+  // Small launches -- at most a.static_rounds problems per wave -- are split STATICALLY, round by round, in slot-major wave order (first one wave on
+  // every SIMD of every CU, then the second wave of every SIMD, ...): no ticket at all.  A wave must otherwise wait for a ticket just to
+  // learn that nothing is left, and 3 072 waves asking one counter word at ~88 M atomics/s is 35 us -- as long as the whole first round of
+  // BASELINE configs[1] (4 096 problems).  A partial round then also lands one wave per SIMD instead of three per SIMD on a third of the CUs.
+  const long long waves_all = (long long)gridDim.x * WAVES;
+  const bool st_rounds = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * waves_all;   // wave-uniform
   auto chunk_for = [&](long long observed) -> int {
+    if (st_rounds) return 1;
     const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
-  auto take_ticket = [&](int chunk) -> unsigned long long {
+  auto take_ticket = [&](int chunk, long long p_now) -> unsigned long long {
+    if (st_rounds) return (unsigned long long)p_now;   // static rounds: the next problem of this wave is p_now + waves_all (= "ticket" p_now + ticket_base)
     unsigned long long t = 0;
     if (lane_id() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
@@ -1598,7 +1622,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
-  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
+  long long p = st_rounds ? (long long)(wave >> 2) * ((long long)gridDim.x * 4) + (long long)blockIdx.x * 4 + (wave & 3) : ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -1613,7 +1637,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     unsigned long long next_ticket = 0;
     if (last_of_chunk) {
       next_chunk = chunk_for(p);
-      next_ticket = take_ticket(next_chunk);
+      next_ticket = take_ticket(next_chunk, p);
     }
     if (ka->skip && ka->skip[p * ka->skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
       if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
@@ -2272,6 +2296,9 @@ const char* fused_name(const KernelArgs& a, int) {
 
 hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t stream) {
   KernelArgs a = a_in;
+  // static rounds up to this many problems per wave (mo_kernels.h; measured): equal-cost work (step, Iterate, residual,
+  // linearisation) splits statically further than a Solve, whose problems need different numbers of passes
+  if (a.static_rounds < 0) a.static_rounds = a.mode == MODE_SOLVE ? (a.n > 32 ? 2 : 6) : (a.n > 32 ? 8 : 32);
   static const int env_stagger = [] { const char* e = getenv("MO_FUSED_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
   // the 64-variable grid of the step kernel with J-level input (the BASELINE configs[2] / [4] shape); measured neutral elsewhere
   const bool headline_shape = a.mode == MODE_STEP && a.J && a.n > 32 && a.n <= 64;
@@ -2285,7 +2312,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);
   const int sw = (env_sw >= 0 && env_sw <= 6) ? env_sw : 3;
   long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
-  const long long blocks_needed = (a.batch + 4 * wps - 1) / (4 * wps);
+  const long long blocks_needed = (a.batch + 3) / 4;
   if (grid > blocks_needed) grid = blocks_needed;
   if (grid < 1) grid = 1;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
@@ -2302,7 +2329,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   if (a.mode == MODE_LINEARIZE) {
     const int wl = a.n > 96 ? 1 : (a.n > 64 ? 2 : 3);
     long long lgrid = num_cus;
-    const long long lneed = (a.batch + 4 * wl - 1) / (4 * wl);
+    const long long lneed = (a.batch + 3) / 4;
     if (lgrid > lneed) lgrid = lneed;
     if (lgrid < 1) lgrid = 1;
     const dim3 lgd((unsigned)lgrid), lbd(256 * wl);
@@ -2316,7 +2343,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
     const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
     const int wf = (a.n > 32 && solve) ? 2 : 3;
     long long fgrid = num_cus;
-    const long long fneed = (a.batch + 4 * wf - 1) / (4 * wf);
+    const long long fneed = (a.batch + 3) / 4;
     if (fgrid > fneed) fgrid = fneed;
     if (fgrid < 1) fgrid = 1;
     const dim3 fgd((unsigned)fgrid), fbd(256 * wf);
@@ -2332,7 +2359,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   if (a.mode == MODE_STEP && a.m > 64) {  // two constraint slots per lane (a box on every one of 64 variables is m = 128)
     const int wq = a.n > 96 ? 1 : (a.n > 32 ? 2 : 3);
     long long qgrid = num_cus;
-    const long long qneed = (a.batch + 4 * wq - 1) / (4 * wq);
+    const long long qneed = (a.batch + 3) / 4;
     if (qgrid > qneed) qgrid = qneed;
     if (qgrid < 1) qgrid = 1;
     const dim3 qgd((unsigned)qgrid), qbd(256 * wq);
@@ -2351,7 +2378,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   if (a.m > 64) {  // Solve / Iterate with two constraint slots per lane (n <= 64, checked by fused_supported)
     const int wq = a.n > 32 ? 2 : 3;
     long long qgrid = num_cus;
-    const long long qneed = (a.batch + 4 * wq - 1) / (4 * wq);
+    const long long qneed = (a.batch + 3) / 4;
     if (qgrid > qneed) qgrid = qneed;
     if (qgrid < 1) qgrid = 1;
     const dim3 qgd((unsigned)qgrid), qbd(256 * wq);
@@ -2368,7 +2395,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
     const bool big = a.n > 96, solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
     const int bw = (!big && !solve) ? 2 : 1;
     long long bgrid = num_cus;
-    const long long bneed = (a.batch + 4 * bw - 1) / (4 * bw);
+    const long long bneed = (a.batch + 3) / 4;
     if (bgrid > bneed) bgrid = bneed;
     if (bgrid < 1) bgrid = 1;
     const dim3 bgd((unsigned)bgrid), bbd(256 * bw);
@@ -2384,7 +2411,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   if (a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL) {  // register budget of the Solve kernel: 2 waves per SIMD at n = 64, 3 at n = 32
     const int swps = a.n > 32 ? 2 : 3;
     long long sgrid = num_cus;
-    const long long need = (a.batch + 4 * swps - 1) / (4 * swps);
+    const long long need = (a.batch + 3) / 4;
     if (sgrid > need) sgrid = need;
     if (sgrid < 1) sgrid = 1;
     const dim3 sgd((unsigned)sgrid), sbd(256 * swps);

@@ -377,11 +377,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
   const int nsteps = m_r >> 2;
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  // Small launches -- at most a.static_rounds problems per wave -- are split STATICALLY, round by round, in slot-major wave order (first one wave on
+  // every SIMD of every CU, then the second wave of every SIMD, ...): no ticket at all.  A wave must otherwise wait for a ticket just to
+  // learn that nothing is left, and 3 072 waves asking one counter word at ~88 M atomics/s is 35 us -- as long as the whole first round of
+  // BASELINE configs[1] (4 096 problems).  A partial round then also lands one wave per SIMD instead of three per SIMD on a third of the CUs.
+  const long long waves_all = (long long)gridDim.x * WAVES;
+  const bool st_rounds = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * waves_all;   // wave-uniform
   auto chunk_for = [&](long long observed) -> int {
+    if (st_rounds) return 1;
     const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
-  auto take_ticket = [&](int chunk) -> unsigned long long {
+  auto take_ticket = [&](int chunk, long long p_now) -> unsigned long long {
+    if (st_rounds) return (unsigned long long)p_now;   // static rounds: the next problem of this wave is p_now + waves_all (= "ticket" p_now + ticket_base)
     unsigned long long t = 0;
     if (lane_id32() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     for (int i = lane_id32() * 16; i < D * SLOT; i += 64 * 16) *(f4*)(smem + i) = f4{0.0f, 0.0f, 0.0f, 0.0f};
     lds_fence32();
   }
-  if (a.stagger > 0) {  // start stagger between the waves that share a SIMD (see kkt_fused.hip): equal-cost problems keep waves in lockstep
+  if (a.stagger > 0 && !st_rounds) {  // start stagger between the waves that share a SIMD (see kkt_fused.hip): equal-cost problems keep waves in lockstep
     const int slot = wave >> 2;
     for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
   // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
-  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
+  long long p = st_rounds ? (long long)(wave >> 2) * ((long long)gridDim.x * 4) + (long long)blockIdx.x * 4 + (wave & 3) : ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 #ifdef MO_F32_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
     unsigned long long next_ticket = 0;
     if (last_of_chunk) {
       next_chunk = chunk_for(p);
-      next_ticket = take_ticket(next_chunk);
+      next_ticket = take_ticket(next_chunk, p);
     }
     const int lane = lane_id32();
     const int g = lane >> 4, j = lane & 15;
@@ -810,11 +818,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
   const bool qpl = a.J == nullptr;  // wave-uniform: QP-level input (G, c given)
 
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  // Small launches -- at most a.static_rounds problems per wave -- are split STATICALLY, round by round, in slot-major wave order (first one wave on
+  // every SIMD of every CU, then the second wave of every SIMD, ...): no ticket at all.  A wave must otherwise wait for a ticket just to
+  // learn that nothing is left, and 3 072 waves asking one counter word at ~88 M atomics/s is 35 us -- as long as the whole first round of
+  // BASELINE configs[1] (4 096 problems).  A partial round then also lands one wave per SIMD instead of three per SIMD on a third of the CUs.
+  const long long waves_all = (long long)gridDim.x * WAVES;
+  const bool st_rounds = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * waves_all;   // wave-uniform
   auto chunk_for = [&](long long observed) -> int {
+    if (st_rounds) return 1;
     const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
-  auto take_ticket = [&](int chunk) -> unsigned long long {
+  auto take_ticket = [&](int chunk, long long p_now) -> unsigned long long {
+    if (st_rounds) return (unsigned long long)p_now;   // static rounds: the next problem of this wave is p_now + waves_all (= "ticket" p_now + ticket_base)
     unsigned long long t = 0;
     if (lane_id32() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
@@ -828,7 +844,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
   // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
-  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
+  long long p = st_rounds ? (long long)(wave >> 2) * ((long long)gridDim.x * 4) + (long long)blockIdx.x * 4 + (wave & 3) : ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
 
   while (p < a.batch) {
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_solve_kernel(con
     unsigned long long next_ticket = 0;
     if (last_of_chunk) {
       next_chunk = chunk_for(p);
-      next_ticket = take_ticket(next_chunk);
+      next_ticket = take_ticket(next_chunk, p);
     }
     if (ka->skip && ka->skip[p * ka->skip_stride] >= 0) {  // wave-uniform: a problem the caller's outer loop has finished with
       if (last_of_chunk) { p = uniform64(next_ticket) + ticket_base; chunk_end = p + next_chunk; } else { ++p; }
@@ -1409,11 +1425,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
   const int nsteps = a.m_r >> 2;
   const int chunk_shift = 63 - __builtin_clzll((unsigned long long)gridDim.x * WAVES * 4);
+  // Small launches -- at most a.static_rounds problems per wave -- are split STATICALLY, round by round, in slot-major wave order (first one wave on
+  // every SIMD of every CU, then the second wave of every SIMD, ...): no ticket at all.  A wave must otherwise wait for a ticket just to
+  // learn that nothing is left, and 3 072 waves asking one counter word at ~88 M atomics/s is 35 us -- as long as the whole first round of
+  // BASELINE configs[1] (4 096 problems).  A partial round then also lands one wave per SIMD instead of three per SIMD on a third of the CUs.
+  const long long waves_all = (long long)gridDim.x * WAVES;
+  const bool st_rounds = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * waves_all;   // wave-uniform
   auto chunk_for = [&](long long observed) -> int {
+    if (st_rounds) return 1;
     const long long c = (a.batch - observed) >> chunk_shift;
     return c < 1 ? 1 : (c > 8 ? 8 : (int)c);
   };
-  auto take_ticket = [&](int chunk) -> unsigned long long {
+  auto take_ticket = [&](int chunk, long long p_now) -> unsigned long long {
+    if (st_rounds) return (unsigned long long)p_now;   // static rounds: the next problem of this wave is p_now + waves_all (= "ticket" p_now + ticket_base)
     unsigned long long t = 0;
     if (lane_id32() == 0) t = atomicAdd(a.ticket, (unsigned long long)chunk);
     return t;
@@ -1427,13 +1451,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_linearize_kernel
   // of a small launch (BASELINE configs[1]: 4 096 problems) and 2 % of the headline one.
   int chunk = chunk_for(0);
   const long long ticket_base = (long long)gridDim.x * WAVES * chunk;
-  long long p = ((long long)blockIdx.x * WAVES + wave) * chunk;
+  long long p = st_rounds ? (long long)(wave >> 2) * ((long long)gridDim.x * 4) + (long long)blockIdx.x * 4 + (wave & 3) : ((long long)blockIdx.x * WAVES + wave) * chunk;
   long long chunk_end = p + chunk;
   while (p < a.batch) {
     const bool last_of_chunk = p + 1 >= chunk_end;
     int next_chunk = 0;
     unsigned long long next_ticket = 0;
-    if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk); }
+    if (last_of_chunk) { next_chunk = chunk_for(p); next_ticket = take_ticket(next_chunk, p); }
     const int lane = lane_id32();
     const int g = lane >> 4, j = lane & 15;
     const char* jsrc = reinterpret_cast<const char*>((const float*)a.J + p * a.J_stride + (size_t)g * N + 4 * j);
@@ -1613,15 +1637,17 @@ const char* fused_f32_name(const KernelArgs& a) {
 
 hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t stream) {
   KernelArgs a = a_in;
+  // static rounds up to this many problems per wave (mo_kernels.h; measured): equal-cost work (step, Iterate, residual,
+  // linearisation) splits statically further than a Solve, whose problems need different numbers of passes
+  if (a.static_rounds < 0) a.static_rounds = a.mode == MODE_SOLVE ? (a.n > 32 ? 2 : 6) : (a.n > 32 ? 8 : 32);
   static const int env_stagger = [] { const char* e = getenv("MO_FUSED_F32_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
   a.stagger = env_stagger >= 0 ? env_stagger : 0;
   hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
   if (a.mode == MODE_LINEARIZE) {
-    const int wps = a.n > 64 ? 2 : 3;
-    long long grid = num_cus;
-    const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+    long long grid = num_cus;   // (two waves per SIMD at n = 128, three at n = 64)
+    const long long need = (a.batch + 3) / 4;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     if (a.n > 64) hipLaunchKernelGGL((kkt_fused_f32_linearize_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, stream, a);
@@ -1629,9 +1655,8 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
     return hipGetLastError();
   }
   if (a.mode != MODE_STEP) {  // Solve / Iterate / KKT residual: one wave per SIMD at n = 128 (216 tile registers + the state), three at n = 64
-    const int wps = a.n > 64 ? 1 : 3;
     long long grid = num_cus;
-    const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+    const long long need = (a.batch + 3) / 4;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     if (a.n > 64) { if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1, false>), dim3((unsigned)grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<8, 1, true>), dim3((unsigned)grid), dim3(256), 0, stream, a); }
@@ -1641,7 +1666,7 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   if (a.n > 64 && env_wps == 1) {
     constexpr int WPS = 1;
     long long grid = num_cus;
-    const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
+    const long long need = (a.batch + 3) / 4;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
@@ -1649,7 +1674,7 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   } else if (a.n > 64) {
     constexpr int WPS = 2;  // 255 VGPRs, no scratch: the 216 accumulator registers + operands just fit two waves per SIMD
     long long grid = num_cus;
-    const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
+    const long long need = (a.batch + 3) / 4;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
@@ -1657,7 +1682,7 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   } else {
     constexpr int WPS = 3;
     long long grid = num_cus;
-    const long long need = (a.batch + 4 * WPS - 1) / (4 * WPS);
+    const long long need = (a.batch + 3) / 4;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     if (a.n == 64) hipLaunchKernelGGL((kkt_fused_f32_kernel<4, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);

@@ -12,7 +12,7 @@ hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t str
   // waves per SIMD: the register budgets of the fast-path instantiations
   const int wps = solve ? (grid_tile == 2 ? 3 : grid_tile == 4 ? 2 : 1) : (grid_tile == 2 || grid_tile == 4 ? 3 : grid_tile == 6 ? 2 : 1);
   long long grid = num_cus;
-  const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+  const long long need = (a.batch + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
   const dim3 gd((unsigned)grid), bd(256 * wps);

@@ -13,7 +13,7 @@ hipError_t launch_fused_mc4(const KernelArgs& a, int num_cus, hipStream_t stream
   const int grid_tile = a.n > 96 ? 8 : a.n > 64 ? 6 : a.n > 32 ? 4 : 2;
   const int wps = grid_tile == 2 ? 3 : grid_tile == 4 ? 2 : 1;
   long long grid = num_cus;
-  const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+  const long long need = (a.batch + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
   const dim3 gd((unsigned)grid), bd(256 * wps);

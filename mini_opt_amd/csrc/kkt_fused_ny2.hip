@@ -19,7 +19,7 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
   // J-level input: 16-byte pieces of a packed row-major J, or the per-lane gather stream for every other layout (odd n included)
   const bool gather = a.J && (fused_needs_gather(a) || (a.n & 1));
   long long grid = num_cus;
-  const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+  const long long need = (a.batch + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
   const dim3 gd((unsigned)grid), bd(256 * wps);

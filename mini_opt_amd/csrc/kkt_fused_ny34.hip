@@ -13,7 +13,7 @@ hipError_t launch_fused_ny34(const KernelArgs& a, int num_cus, hipStream_t strea
   const bool big = a.n > 32, four = a.k > 47;
   const int wps = big ? 1 : (four ? 2 : (solve ? 2 : 3));
   long long grid = num_cus;
-  const long long need = (a.batch + 4 * wps - 1) / (4 * wps);
+  const long long need = (a.batch + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
   const dim3 gd((unsigned)grid), bd(256 * wps);

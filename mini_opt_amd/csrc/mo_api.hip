@@ -103,6 +103,13 @@ bool generic_forced(const mo_plan* plan) {
   return env_force_generic || (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
 }
 
+// Launches of at most this many problems per wave of the persistent grid are split statically (KernelArgs::static_rounds): -1 = the launcher's
+// own choice per kernel family (launch_fused / launch_fused_f32); A/B knob MO_FUSED_STATIC_ROUNDS (0 = tickets always)
+int fused_static_rounds() {
+  static const int v = [] { const char* e = getenv("MO_FUSED_STATIC_ROUNDS"); return e ? atoi(e) : -1; }();
+  return v;
+}
+
 KernelChoice choose_kernel(const mo_plan* plan, const mo::KernelArgs& a) {
   if (!generic_forced(plan)) {
     if (mo::fused_supported(a, plan->desc.dtype)) return KERNEL_FUSED_F64;
@@ -114,7 +121,7 @@ KernelChoice choose_kernel(const mo_plan* plan, const mo::KernelArgs& a) {
 int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice choice, void* stream) {
   if (a_in.batch == 0) return MO_OK;
   mo::KernelArgs a = a_in;
-  a.ticket = plan->ticket; a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   MO_HIP_CHECK(hipSetDevice(plan->desc.device));
   hipStream_t s = (hipStream_t)stream;
   if (choice == KERNEL_FUSED_F64) {
@@ -143,7 +150,7 @@ int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice 
 
 int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
   mo::KernelArgs a = a_in;
-  a.ticket = plan->ticket; a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   return launch_chosen(plan, a, choose_kernel(plan, a), stream);
 }
 
@@ -268,7 +275,7 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   a.mode = mo::MODE_STEP;
   a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned, densely packed state / output
   a.vars_stride = a.delta_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
-  a.ticket = plan->ticket; a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   switch (choose_kernel(plan, a)) {
     case KERNEL_FUSED_F64: return mo::fused_name(a, plan->desc.dtype);
     case KERNEL_FUSED_F32: return mo::fused_f32_name(a);
@@ -283,7 +290,7 @@ const char* mo_plan_solve_kernel(const mo_plan* plan, const mo_problem* prob) {
   a.mode = mo::MODE_SOLVE;
   a.vars = reinterpret_cast<void*>(16);  // layout query only
   a.vars_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
-  a.ticket = plan->ticket; a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   switch (choose_kernel(plan, a)) {
     case KERNEL_FUSED_F64: return mo::fused_name(a, plan->desc.dtype);
     case KERNEL_FUSED_F32: return mo::fused_f32_name(a);
@@ -467,7 +474,7 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
   a.termination = termination; a.num_iterations = num_iterations; a.iterations = iterations; a.lagrange = lagrange;
   a.status = status;
   a.skip = skip; a.skip_stride = skip_stride; a.skip_active = skip_active;
-  a.ticket = plan->ticket; a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   const KernelChoice choice = choose_kernel(plan, a);
   const bool use_fused = choice != KERNEL_GENERIC;
   if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch

@@ -56,6 +56,11 @@ struct KernelArgs {
   unsigned long long* ticket;
   int stagger;     // fused step kernel: start offset between the waves that share a SIMD, in units of 127 x 64 cycles (set by launch_fused)
   int chain_prio;  // fused step kernel: s_setprio 1 while a wave is in the elimination / substitution chains
+  int static_rounds;  // fused kernels: launches of at most this many problems per wave are split statically, round by round, with no ticket
+                      // (mo_api.hip hands over -1 = "the launcher decides" or MO_FUSED_STATIC_ROUNDS; 0 = tickets always).  The grids are
+                      // min(CUs, ceil(batch / 4)) workgroups, so that a small batch spreads one wave per SIMD over the CUs before any SIMD
+                      // gets a second wave.  Measured: the 32-variable grid wins with static rounds at every batch up to
+                      // 65 536 (21 rounds), the 64 grid and the fp32 128 grid up to ~8 rounds; beyond, tickets in guided chunks balance better.
   int no_tiny;     // MO_PLAN_NO_TINY: keep n + k <= 15 on the 32-variable tile grid (set by mo_api.hip from the plan flags)
   // generic kernel beyond its LDS-resident range: P x ldh workspace of H per workgroup of the persistent grid (plan-owned)
   void* H_work; long long H_work_stride;
