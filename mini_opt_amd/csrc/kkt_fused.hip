@@ -2315,8 +2315,23 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   const long long blocks_needed = (a.batch + 3) / 4;
   if (grid > blocks_needed) grid = blocks_needed;
   if (grid < 1) grid = 1;
-  hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+  // The work counter is zeroed on the stream in front of the kernel -- unless the launch is certain to run in static rounds, which never touch
+  // it: every kernel below has at least 4 waves per workgroup and min(CUs, ceil(batch / 4)) workgroups, so batch <= rounds x 4 x workgroups
+  // is static whatever the instantiation (the kernels test batch <= rounds x waves).  One enqueued operation less per small launch.
+  {
+    long long wgs = (a.batch + 3) / 4;
+    if (wgs > num_cus) wgs = num_cus;
+#if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)
+    const bool tickets_always = fused_tiny_supported(a);   // the one-tile kernel hands out tickets of up to 64 problems whatever the size
+#else
+    const bool tickets_always = false;
+#endif
+    const bool surely_static = !tickets_always && a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * 4 * wgs;
+    if (!surely_static) {
+      hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
+      if (e != hipSuccess) return e;
+    }
+  }
 #if !defined(MO_FUSED_STAMPS) && !defined(MO_GENERIC_STAMPS)  // (the diagnostic builds of tools/phase_timer*.hip link this file alone)
   if (fused_tiny_supported(a)) return launch_fused_tiny(a, num_cus, stream);
   if (a.mode != MODE_LINEARIZE && a.k <= 15 && !fused_needs_gather(a) && !(a.J && (a.n & 1)) &&

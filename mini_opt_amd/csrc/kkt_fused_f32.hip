@@ -1642,8 +1642,18 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   if (a.static_rounds < 0) a.static_rounds = a.mode == MODE_SOLVE ? (a.n > 32 ? 2 : 6) : (a.n > 32 ? 8 : 32);
   static const int env_stagger = [] { const char* e = getenv("MO_FUSED_F32_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
   a.stagger = env_stagger >= 0 ? env_stagger : 0;
-  hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
-  if (e != hipSuccess) return e;
+  // The work counter is zeroed on the stream in front of the kernel -- unless the launch is certain to run in static rounds, which never touch
+  // it: every kernel below has at least 4 waves per workgroup and min(CUs, ceil(batch / 4)) workgroups, so batch <= rounds x 4 x workgroups
+  // is static whatever the instantiation (the kernels test batch <= rounds x waves).  One enqueued operation less per small launch.
+  {
+    long long wgs = (a.batch + 3) / 4;
+    if (wgs > num_cus) wgs = num_cus;
+    const bool surely_static = a.static_rounds > 0 && a.batch <= (long long)a.static_rounds * 4 * wgs;
+    if (!surely_static) {
+      hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned long long), stream);
+      if (e != hipSuccess) return e;
+    }
+  }
   static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
   if (a.mode == MODE_LINEARIZE) {
     long long grid = num_cus;   // (two waves per SIMD at n = 128, three at n = 64)
