@@ -272,70 +272,115 @@ __device__ inline void jtj_tile_rows_impl(const Ws<T>& w, int n, int rows, int t
       if (i < n && j <= i) w.H[i + (size_t)j * w.ldh] += acc[bi * (bi + 1) / 2 + bj];
     }
 }
-// LARGE: the same register tiling over 96 x 96 super-blocks of G (16 x 16 threads x 6 x 6 blocks), lower block triangle only.  G is in global
-// memory, so the super-block is the OUTER loop: its 36 accumulators stay in registers over all rows of J and are stored once (first version:
-// chunk of rows outside, read-modify-write of G per chunk -- 9 MB of workspace traffic per problem at n = 256, the kernel's bound).  Per
-// super-block only the columns [I0, I0 + wi) and [J0, J0 + wj) of J are staged (wj = 0 on the diagonal), `rows` of them at a time.
-template <typename T, bool DIAG>
-__device__ inline void jtj_superblock_rows(const T* Jc, int wc, int wi, int wj, int rows, int ti, int tj, T (&acc)[36]) {
-  constexpr int TG = 16, RN = 6;
-  int ic[RN], jc[RN];
-#pragma unroll
-  for (int b = 0; b < RN; ++b) {   // clamped local column indices: out-of-range operands are read (in bounds) and their results never stored
-    ic[b] = ti + TG * b < wi ? ti + TG * b : wi - 1;
-    jc[b] = DIAG ? (tj + TG * b < wi ? tj + TG * b : wi - 1) : wi + (tj + TG * b < wj ? tj + TG * b : wj - 1);
-  }
-  for (int q = 0; q < rows; ++q) {
-    const T* row = Jc + (size_t)q * wc;
-    T a[RN], b[RN];
-#pragma unroll
-    for (int e = 0; e < RN; ++e) { a[e] = row[ic[e]]; b[e] = row[jc[e]]; }
-#pragma unroll
-    for (int bi = 0; bi < RN; ++bi)
-#pragma unroll
-      for (int bj = 0; bj < RN; ++bj)
-        if (!DIAG || bj <= bi) acc[bi * RN + bj] += a[bi] * b[bj];
-  }
-}
+// LARGE: J^T J over 96 x 96 super-blocks of G (6 x 6 tiles of 16 x 16), lower block triangle only, ON THE MATRIX CORES.  G is in global
+// memory, so the super-block is the OUTER loop: its accumulators stay in registers over all rows of J and are stored once.  Per super-block
+// only the columns [I0, I0 + wi) and [J0, J0 + wj) of J are staged (wj = 0 on the diagonal), `rows` of them at a time, rows padded with zeros
+// to a multiple of 4 (one v_mfma_*_16x16x4 consumes 4 rows of J).  Each of the four waves owns a 3 x 3 quadrant of the tiles.  A tile is
+// computed TRANSPOSED, D[jl][il] = sum_q J[q][J0 + jl] J[q][I0 + il] (A operand from the J block, B operand from the I block): the lanes of
+// a 16-lane row then hold 16 consecutive ROWS of G and the stores to the column-major workspace are whole 128-byte segments.  The staged rows
+// have a stride of (columns + 16) elements: a multiple of 32 plus 16, so the four rows an operand read touches fall on disjoint LDS banks.
+// (Round 3, first version: 16 x 16 threads x 6 x 6 register blocks on the VALU, 12 LDS reads per 36 FMAs per row of J and thread.)
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+  typedef v4f64 Acc;
+  __device__ static inline Acc mac(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  __device__ static inline int row(int g, int t) { return g + 4 * t; }    // C/D fragment: lane (g, l), register t <-> (row g + 4 t, col l)
+};
+template <> struct Mfma16<float> {
+  typedef v4f32 Acc;
+  __device__ static inline Acc mac(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  __device__ static inline int row(int g, int t) { return 4 * g + t; }    // (row 4 g + t, col l)
+};
+__host__ __device__ inline int large_jtj_stride(int wc) { return wc + 16 + ((32 - (wc & 31)) & 31); }   // = 16 (mod 32), >= wc + 16
+#ifndef MO_LARGE_TQ
+#define MO_LARGE_TQ 4
+#endif
 template <typename T>
 __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r, int tid) {
-  constexpr int TG = 16, RN = 6, SBW = TG * RN;
-  const int ti = tid & (TG - 1), tj = tid / TG, lane = tid & 63, wave = tid >> 6, nwaves = kThreads >> 6;
+  typedef Mfma16<T> MF;
+  typedef typename MF::Acc Acc;
+  constexpr int TQ = MO_LARGE_TQ, SBW = 32 * TQ;   // a wave's quadrant is TQ x TQ tiles, the super-block 2 TQ x 2 TQ
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l = lane & 15;
+  const int qa = (wave >> 1) & 1, qb = wave & 1;             // this wave's quadrant of the tiles: I tiles TQ qa .., J tiles TQ qb ..
   for (int I0 = 0; I0 < n; I0 += SBW) {
     const int wi = n - I0 < SBW ? n - I0 : SBW;
     for (int J0 = 0; J0 <= I0; J0 += SBW) {
       const bool diag = J0 == I0;
       const int wj = diag ? 0 : SBW, wc = wi + wj;          // (J0 < I0: a full block of columns)
-      int CR = w.region / (wc + 1);
-      if (CR > m_r) CR = m_r;
-      T* const rcs = w.Jc + (size_t)CR * wc;               // r of the staged rows
-      T acc[RN * RN];
+      const int ws = large_jtj_stride(wc);
+      int CR = (w.region / (ws + 1)) & ~3;
+      if (CR > ((m_r + 3) & ~3)) CR = (m_r + 3) & ~3;
+      T* const rcs = w.Jc + (size_t)CR * ws;               // r of the staged rows
+      // which of the wave's TQ x TQ tiles exist (wave-uniform): inside the block's columns, and on / below the diagonal of a diagonal block
+      const int jw = diag ? wi : wj, joff = diag ? 0 : wi;
+      bool need[TQ][TQ];
+      bool any = false;
 #pragma unroll
-      for (int e = 0; e < RN * RN; ++e) acc[e] = (T)0;
-      for (int q0 = 0; q0 < m_r; q0 += CR) {
-        const int rows = m_r - q0 < CR ? m_r - q0 : CR;
-        if (row_major) {
-          for (int q = wave; q < rows; q += nwaves) {
-            const T* src = J + (size_t)(q0 + q) * J_ld;
-            for (int cx = lane; cx < wc; cx += 64) w.Jc[(size_t)q * wc + cx] = src[cx < wi ? I0 + cx : J0 + cx - wi];
-          }
-        } else {
-          for (int cx = wave; cx < wc; cx += nwaves) {
-            const T* src = J + (size_t)(cx < wi ? I0 + cx : J0 + cx - wi) * J_ld + q0;
-            for (int q = lane; q < rows; q += 64) w.Jc[(size_t)q * wc + cx] = src[q];
-          }
+      for (int a_ = 0; a_ < TQ; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < TQ; ++b_) {
+          need[a_][b_] = wave < 4 && 16 * (TQ * qa + a_) < wi && 16 * (TQ * qb + b_) < jw && (!diag || TQ * qb + b_ <= TQ * qa + a_);
+          any = any || need[a_][b_];
         }
+      int ic[TQ], jc[TQ];                                    // clamped local columns: out-of-range operands are read (in bounds), their results never stored
+#pragma unroll
+      for (int e = 0; e < TQ; ++e) {
+        const int ci = 16 * (TQ * qa + e) + l, cj = 16 * (TQ * qb + e) + l;
+        ic[e] = ci < wi ? ci : wi - 1;
+        jc[e] = joff + (cj < jw ? cj : jw - 1);
+      }
+      Acc acc[TQ][TQ];
+#pragma unroll
+      for (int a_ = 0; a_ < TQ; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < TQ; ++b_) acc[a_][b_] = Acc{(T)0, (T)0, (T)0, (T)0};
+      for (int q0 = 0; q0 < m_r; q0 += CR) {
+        const int rows = m_r - q0 < CR ? m_r - q0 : CR, rows4 = (rows + 3) & ~3;
+        // staging: every thread issues a batch of loads before it stores any of them (one round of global-memory latency per batch, not per
+        // element: the first version's element-by-element copy was most of the phase)
+        for (int base = 0; base < rows * wc; base += 8 * kThreads) {
+          T v[8];
+          int dst[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * kThreads + tid;
+            dst[e] = -1;
+            v[e] = (T)0;
+            if (idx < rows * wc) {
+              int q, cx;
+              if (row_major) { q = idx / wc; cx = idx - q * wc; } else { cx = idx / rows; q = idx - cx * rows; }
+              const int col = cx < wi ? I0 + cx : J0 + cx - wi;
+              v[e] = row_major ? J[(size_t)(q0 + q) * J_ld + col] : J[(size_t)col * J_ld + q0 + q];
+              dst[e] = q * ws + cx;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (dst[e] >= 0) w.Jc[dst[e]] = v[e];
+        }
+        for (int idx = tid; idx < (rows4 - rows) * wc; idx += kThreads) w.Jc[(size_t)(rows + idx / wc) * ws + idx % wc] = (T)0;
         if (diag)
           for (int idx = tid; idx < rows; idx += kThreads) rcs[idx] = r[q0 + idx];
         __syncthreads();
-        if (tid < TG * TG) {
-          if (diag) jtj_superblock_rows<T, true>(w.Jc, wc, wi, wj, rows, ti, tj, acc);
-          else jtj_superblock_rows<T, false>(w.Jc, wc, wi, wj, rows, ti, tj, acc);
+        if (any) {
+          for (int q = 0; q < rows4; q += 4) {
+            const T* row = w.Jc + (size_t)(q + g) * ws;
+            T bi[TQ], aj[TQ];
+#pragma unroll
+            for (int e = 0; e < TQ; ++e) { bi[e] = row[ic[e]]; aj[e] = row[jc[e]]; }
+#pragma unroll
+            for (int a_ = 0; a_ < TQ; ++a_)
+#pragma unroll
+              for (int b_ = 0; b_ < TQ; ++b_)
+                if (need[a_][b_]) acc[a_][b_] = MF::mac(aj[b_], bi[a_], acc[a_][b_]);
+          }
         }
         if (diag) {                                          // c = J^T r for the columns of this diagonal block; 0.5 |r|^2 once
           for (int i = tid; i < wi; i += kThreads) {
             T cacc = 0;
-            for (int q = 0; q < rows; ++q) cacc += w.Jc[(size_t)q * wc + i] * rcs[q];
+            for (int q = 0; q < rows; ++q) cacc += w.Jc[(size_t)q * ws + i] * rcs[q];
             w.cvec[I0 + i] += cacc;
           }
           if (I0 == 0 && tid == 0) {
@@ -346,15 +391,18 @@ __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, cons
         }
         __syncthreads();
       }
-      if (tid < TG * TG) {
 #pragma unroll
-        for (int bi = 0; bi < RN; ++bi)
+      for (int a_ = 0; a_ < TQ; ++a_)
 #pragma unroll
-          for (int bj = 0; bj < RN; ++bj) {
-            const int i = I0 + ti + TG * bi, j = J0 + tj + TG * bj;
-            if ((!diag || bj <= bi) && i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] = acc[bi * RN + bj];
+        for (int b_ = 0; b_ < TQ; ++b_) {
+          if (!need[a_][b_]) continue;
+          const int i = I0 + 16 * (TQ * qa + a_) + l;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int j = J0 + 16 * (TQ * qb + b_) + MF::row(g, t);
+            if (i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] = acc[a_][b_][t];
           }
-      }
+        }
     }
   }
 }
@@ -368,6 +416,8 @@ __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T
   __syncthreads();
   if constexpr (LARGE) {
     accumulate_jtj_large<T>(w, n, m_r, J, J_ld, row_major, r, tid);
+    __threadfence_block();   // the diagonal of G was stored by other threads than the ones that add lambda to it
+    __syncthreads();
     if (lambda > (T)0)
       for (int i = tid; i < n; i += kThreads) w.H[i + (size_t)i * w.ldh] += lambda;
     if (tid == 0) w.red[8] *= (T)0.5;
@@ -611,44 +661,55 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
       if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = panel[i + (size_t)jj * ldp];
     }
     const int tr = rows - wd;                                                    // trailing rows / columns
-    if (tr > 0) {
-      const int ti = tid & 15, tj = (tid >> 4) & 15;
-      if (tid < 256) {
-        for (int I0 = 0; I0 < tr; I0 += 64) {
-          for (int J0 = 0; J0 <= I0; J0 += 64) {
-            T acc[4][4];
-            int ii[4], jj[4];
+    if (tr > 0 && tid < 256) {
+      // H22 -= W21 D^-1 W21^T on the matrix cores, 64 x 64 macro tiles of the lower triangle: wave wv owns the 16 rows I0 + 16 wv .. of a macro
+      // tile and its (up to) four 16 x 16 tiles, each computed transposed (A operand: the column block scaled by 1 / D, B operand: the row
+      // block), so that a 16-lane row holds 16 consecutive rows of H and the read-modify-write moves whole 128-byte segments.  The loads of
+      // H are issued before the products.  Pivots beyond the panel's width contribute zeros (both operands are masked).
+      typedef Mfma16<T> MF;
+      typedef typename MF::Acc Acc;
+      const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, l = lane & 15;
+      for (int I0 = 0; I0 < tr; I0 += 64) {
+        const int ib = I0 + 16 * wv;                                             // first row of this wave's tiles
+        if (ib >= tr) continue;                                                  // (wave-uniform; no barrier inside these loops)
+        const int i = ib + l, irow = wd + (i < tr ? i : tr - 1);
+        for (int J0 = 0; J0 <= I0; J0 += 64) {
+          bool need[4];
+          int jrow[4];
+          Acc acc[4];
+          T hv[4][4];
 #pragma unroll
-            for (int a_ = 0; a_ < 4; ++a_) {
-              ii[a_] = wd + (I0 + ti + 16 * a_ < tr ? I0 + ti + 16 * a_ : tr - 1);
-              jj[a_] = wd + (J0 + tj + 16 * a_ < tr ? J0 + tj + 16 * a_ : tr - 1);
+          for (int b_ = 0; b_ < 4; ++b_) {
+            need[b_] = J0 + 16 * b_ < tr && J0 + 16 * b_ <= ib;                  // exists, and not strictly above the diagonal
+            const int jl = J0 + 16 * b_ + l;
+            jrow[b_] = wd + (jl < tr ? jl : tr - 1);
+            acc[b_] = Acc{(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
-              for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = (T)0;
+            for (int t = 0; t < 4; ++t) {
+              const int j = J0 + 16 * b_ + MF::row(g, t);
+              hv[b_][t] = (need[b_] && i < tr && j <= i) ? w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] : (T)0;
             }
-            for (int q = 0; q < wd; ++q) {
-              const T inv = w.invd[kb + q];
-              T av[4], bv[4];
+          }
+          for (int q = 0; q < wd; q += 4) {
+            const bool valid = q + g < wd;
+            const int kq = valid ? q + g : 0;
+            const T inv = valid ? w.invd[kb + kq] : (T)0;
+            const T bi = valid ? panel[irow + (size_t)kq * ldp] : (T)0;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { av[e] = panel[ii[e] + (size_t)q * ldp]; bv[e] = panel[jj[e] + (size_t)q * ldp] * inv; }
-#pragma unroll
-              for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-                for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] += av[a_] * bv[b_];
+            for (int b_ = 0; b_ < 4; ++b_) {
+              if (!need[b_]) continue;
+              const T aj = valid ? panel[jrow[b_] + (size_t)kq * ldp] * inv : (T)0;
+              acc[b_] = MF::mac(aj, bi, acc[b_]);
             }
+          }
 #pragma unroll
-            for (int a_ = 0; a_ < 4; ++a_)   // two-phase read-modify-write (all 16 loads in flight together, see jtj_superblock)
+          for (int b_ = 0; b_ < 4; ++b_) {
+            if (!need[b_]) continue;
 #pragma unroll
-              for (int b_ = 0; b_ < 4; ++b_) {
-                const int i = I0 + ti + 16 * a_, j = J0 + tj + 16 * b_;
-                if (i < tr && j <= i) acc[a_][b_] = w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] - acc[a_][b_];
-              }
-#pragma unroll
-            for (int a_ = 0; a_ < 4; ++a_)
-#pragma unroll
-              for (int b_ = 0; b_ < 4; ++b_) {
-                const int i = I0 + ti + 16 * a_, j = J0 + tj + 16 * b_;
-                if (i < tr && j <= i) w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] = acc[a_][b_];
-              }
+            for (int t = 0; t < 4; ++t) {
+              const int j = J0 + 16 * b_ + MF::row(g, t);
+              if (i < tr && j <= i) w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] = hv[b_][t] - acc[b_][t];
+            }
           }
         }
       }
