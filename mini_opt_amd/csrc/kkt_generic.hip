@@ -617,6 +617,71 @@ __device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
   return MO_STATUS_OK;
 }
 
+// One column panel of the blocked factorisation with the panel in REGISTERS: thread tid owns rows tid + 256 e (e < RPT) and keeps their wd <=
+// NBR values in registers.  Per pivot the owners of rows j .. wd - 1 publish column j's entries of the diagonal block (one of two alternating
+// LDS buffers at the start of the -- otherwise idle -- panel region), one barrier, and every thread updates its rows with broadcast reads:
+// a handful of instructions per pivot and row where the first version (panel in LDS, elements dealt out by a flat index) spent an integer
+// division, three LDS reads and an LDS write per ELEMENT.  Same arithmetic (one IEEE division per pivot, the same products in the same
+// order), same zero-pivot rules.  Leaves W = L D in H and in the LDS panel (for the trailing update), 1 / D in invd.  Returns the status.
+template <typename T, int NBR, int RPT>
+__device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd, int rows, int ldp, int tid, bool& found_zero) {
+  T a[RPT][NBR];
+#pragma unroll
+  for (int e = 0; e < RPT; ++e) {
+    const int i = tid + 256 * e;
+#pragma unroll
+    for (int jj = 0; jj < NBR; ++jj)
+      a[e][jj] = (i < rows && jj < wd && i >= jj) ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
+  }
+  int status = MO_STATUS_OK;
+#pragma unroll
+  for (int j = 0; j < NBR; ++j) {
+    if (j >= wd || status != MO_STATUS_OK) continue;                              // (uniform)
+    T* const buf = panel + (j & 1) * (NBR + 1);
+    if (tid >= j && tid < wd) buf[tid] = a[0][j];
+    __syncthreads();
+    const T d = buf[j];                                                           // uniform
+    if (!(absT(d) > (T)0)) {                                                      // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
+      bool nz = false;
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) {
+        const int i = tid + 256 * e;
+        nz |= (i > j && i < rows && !(a[e][j] == (T)0));
+      }
+      if (nz || !(d == (T)0)) w.iflag[1] = 1;
+      __syncthreads();
+      if (tid == 0) w.invd[kb + j] = (T)0;
+      if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }
+      found_zero = true;
+      continue;
+    }
+    if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }        // non-zero pivot after a zero pivot
+    const T inv = (T)1 / d;
+    if (tid == 0) w.invd[kb + j] = inv;
+#pragma unroll
+    for (int jj = j + 1; jj < NBR; ++jj) {
+      if (jj >= wd) continue;
+      const T f = buf[jj] * inv;
+#pragma unroll
+      for (int e = 0; e < RPT; ++e) a[e][jj] -= a[e][j] * f;                       // (entries above the diagonal are never read)
+    }
+  }
+  __syncthreads();                                                                // the publish buffers live in the panel region
+  if (status != MO_STATUS_OK) return status;
+#pragma unroll
+  for (int e = 0; e < RPT; ++e) {
+    const int i = tid + 256 * e;
+    if (i < rows) {
+#pragma unroll
+      for (int jj = 0; jj < NBR; ++jj) {
+        if (jj >= wd) continue;
+        panel[i + (size_t)jj * ldp] = a[e][jj];
+        if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = a[e][jj];
+      }
+    }
+  }
+  return status;
+}
 // LARGE: right-looking blocked LDL^T with H in global memory (same natural order, same zero-pivot rules, same result layout: W = L D below
 // the diagonal, invd = 1 / D).  Per block column: the panel (all rows below the diagonal block, NB columns) is staged in LDS and factorised
 // there pivot by pivot (one barrier per pivot); the trailing matrix gets its rank-NB update H22 -= W21 D^-1 W21^T straight in global memory
@@ -628,37 +693,49 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
   int status = MO_STATUS_OK;
   for (int kb = 0; kb < P && status == MO_STATUS_OK; kb += NB) {
     const int wd = P - kb < NB ? P - kb : NB, rows = P - kb, ldp = rows | 1;
-    for (int idx = tid; idx < rows * wd; idx += kThreads) {
-      const int jj = idx / rows, i = idx - jj * rows;
-      panel[i + (size_t)jj * ldp] = i >= jj ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
-    }
-    __syncthreads();
-    for (int j = 0; j < wd; ++j) {
-      const T d = panel[j + (size_t)j * ldp];                                   // uniform
-      if (!(absT(d) > (T)0)) {                                                  // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
-        bool nz = false;
-        for (int i = j + 1 + tid; i < rows; i += kThreads) nz |= !(panel[i + (size_t)j * ldp] == (T)0);
-        if (nz || !(d == (T)0)) w.iflag[1] = 1;
-        __syncthreads();
-        if (tid == 0) w.invd[kb + j] = (T)0;
-        if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }
-        found_zero = true;
-        continue;
+    if (kThreads == 256 && rows <= 512 && NB <= 32) {                            // the panel in registers (uniform)
+      if (NB <= 16) {
+        if (rows <= 256) status = factor_panel_regs<T, 16, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+        else status = factor_panel_regs<T, 16, 2>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+      } else {
+        if (rows <= 256) status = factor_panel_regs<T, 32, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+        else status = factor_panel_regs<T, 32, 2>(w, panel, kb, wd, rows, ldp, tid, found_zero);
       }
-      if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; break; }      // non-zero pivot after a zero pivot
-      const T inv = (T)1 / d;
-      if (tid == 0) w.invd[kb + j] = inv;
-      const int rem = wd - j - 1;
-      for (int idx = tid; idx < rem * rows; idx += kThreads) {                  // the panel's remaining columns
-        const int c = idx / rows, i = idx - c * rows, jj = j + 1 + c;
-        if (i >= jj) panel[i + (size_t)jj * ldp] -= panel[i + (size_t)j * ldp] * (panel[jj + (size_t)j * ldp] * inv);
+      if (status != MO_STATUS_OK) break;                                         // uniform
+      __syncthreads();                                                           // the LDS copy of the panel is read by other threads below
+    } else {                                                                     // any size: the panel in LDS
+      for (int idx = tid; idx < rows * wd; idx += kThreads) {
+        const int jj = idx / rows, i = idx - jj * rows;
+        panel[i + (size_t)jj * ldp] = i >= jj ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
       }
       __syncthreads();
-    }
-    if (status != MO_STATUS_OK) break;                                           // uniform
-    for (int idx = tid; idx < rows * wd; idx += kThreads) {                      // W back to H
-      const int jj = idx / rows, i = idx - jj * rows;
-      if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = panel[i + (size_t)jj * ldp];
+      for (int j = 0; j < wd; ++j) {
+        const T d = panel[j + (size_t)j * ldp];                                   // uniform
+        if (!(absT(d) > (T)0)) {                                                  // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
+          bool nz = false;
+          for (int i = j + 1 + tid; i < rows; i += kThreads) nz |= !(panel[i + (size_t)j * ldp] == (T)0);
+          if (nz || !(d == (T)0)) w.iflag[1] = 1;
+          __syncthreads();
+          if (tid == 0) w.invd[kb + j] = (T)0;
+          if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }
+          found_zero = true;
+          continue;
+        }
+        if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; break; }      // non-zero pivot after a zero pivot
+        const T inv = (T)1 / d;
+        if (tid == 0) w.invd[kb + j] = inv;
+        const int rem = wd - j - 1;
+        for (int idx = tid; idx < rem * rows; idx += kThreads) {                  // the panel's remaining columns
+          const int c = idx / rows, i = idx - c * rows, jj = j + 1 + c;
+          if (i >= jj) panel[i + (size_t)jj * ldp] -= panel[i + (size_t)j * ldp] * (panel[jj + (size_t)j * ldp] * inv);
+        }
+        __syncthreads();
+      }
+      if (status != MO_STATUS_OK) break;                                           // uniform
+      for (int idx = tid; idx < rows * wd; idx += kThreads) {                      // W back to H
+        const int jj = idx / rows, i = idx - jj * rows;
+        if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = panel[i + (size_t)jj * ldp];
+      }
     }
     const int tr = rows - wd;                                                    // trailing rows / columns
     if (tr > 0 && tid < 256) {
