@@ -236,8 +236,13 @@ __device__ MO_INLINE void load_qp(const Ws<T>& w, int n, int k, const T* G, int 
       for (int i = j + tid; i < n; i += kThreads) w.H[i + (size_t)j * w.ldh] = G[i + (size_t)j * G_ld];
     for (int i = tid; i < n; i += kThreads) w.cvec[i] = c[i];
   }
-  for (int j = 0; j < n; ++j)
-    for (int q = tid; q < k; q += kThreads) w.H[n + q + (size_t)j * w.ldh] = A[q + (size_t)j * A_ld];
+  if (k > 0) {   // the k x n block of A_eq as one flat index (k is small: a loop over columns leaves most of the workgroup idle in every round trip)
+#pragma unroll 4
+    for (int idx = tid; idx < n * k; idx += kThreads) {
+      const int j = idx / k, q = idx - j * k;
+      w.H[n + q + (size_t)j * w.ldh] = A[q + (size_t)j * A_ld];
+    }
+  }
   for (int q = tid; q < k; q += kThreads) w.beq[q] = b[q];
   __syncthreads();
 }
@@ -469,11 +474,15 @@ __device__ MO_INLINE void eval_kkt(const Ws<T>& w, int n, int k, int m, bool inc
   T* r_d = w.res; T* r_comp = w.res + n; T* r_pe = w.res + n + m; T* r_pi = w.res + n + m + k;
   for (int i = tid; i < n; i += kThreads) {
     T acc = 0;
+    // (unrolled by 8: with H in a global workspace the eight loads of a group are in flight together; the order of the sum is unchanged)
+#pragma unroll 8
     for (int j = 0; j <= i; ++j) acc += w.H[i + (size_t)j * w.ldh] * x[j];       // selfadjointView<Lower>, :404
+#pragma unroll 8
     for (int j = i + 1; j < n; ++j) acc += w.H[j + (size_t)i * w.ldh] * x[j];
     T rd = acc + w.cvec[i];
     if (k > 0) {
       T acc2 = 0;
+#pragma unroll 8
       for (int q = 0; q < k; ++q) acc2 += w.H[n + q + (size_t)i * w.ldh] * y[q];  // :406
       rd -= acc2;
     }
@@ -485,6 +494,7 @@ __device__ MO_INLINE void eval_kkt(const Ws<T>& w, int n, int k, int m, bool inc
   }
   for (int q = tid; q < k; q += kThreads) {                                       // :408
     T acc = 0;
+#pragma unroll 8
     for (int j = 0; j < n; ++j) acc += w.H[n + q + (size_t)j * w.ldh] * x[j];
     r_pe[q] = acc + w.beq[q];
   }
@@ -812,6 +822,7 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
   const int lane = tid & 63, wave = tid >> 6, nwaves = kThreads >> 6;
   for (int c0 = 0; c0 < P; c0 += SB) {
     const int wd = P - c0 < SB ? P - c0 : SB;
+#pragma unroll 4
     for (int idx = tid; idx < wd * wd; idx += kThreads) {
       const int jj = idx / wd, i = idx - jj * wd;
       dblk[i + jj * ldb] = i > jj ? w.H[(size_t)(c0 + i) + (size_t)(c0 + jj) * w.ldh] : (T)0;
@@ -829,6 +840,7 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
     for (int i = c0 + wd + tid; i < P; i += kThreads) {
       const T* row = w.H + (size_t)i + (size_t)c0 * w.ldh;
       T acc = (T)0;
+#pragma unroll 8
       for (int jj = 0; jj < wd; ++jj) acc += row[(size_t)jj * w.ldh] * tvec[jj];
       w.rhs[i] -= acc;
     }
@@ -837,6 +849,7 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
   const int last = ((P - 1) / SB) * SB;
   for (int c0 = last; c0 >= 0; c0 -= SB) {
     const int wd = P - c0 < SB ? P - c0 : SB, below = c0 + wd;
+#pragma unroll 4
     for (int idx = tid; idx < wd * wd; idx += kThreads) {
       const int jj = idx / wd, i = idx - jj * wd;
       dblk[i + jj * ldb] = i > jj ? w.H[(size_t)(c0 + i) + (size_t)(c0 + jj) * w.ldh] : (T)0;
@@ -844,6 +857,7 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
     for (int jj = wave; jj < wd; jj += nwaves) {
       const T* col = w.H + (size_t)(c0 + jj) * w.ldh;
       T sacc = (T)0;
+#pragma unroll 4
       for (int i = below + lane; i < P; i += 64) sacc += col[i] * w.rhs[i];
       sacc = wave_sum(sacc);
       if (lane == 0) tvec[jj] = sacc;
