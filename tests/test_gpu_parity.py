@@ -1582,6 +1582,46 @@ def test_fused_kernels_take_every_layout_of_J(n, k, m, m_r):
         assert np.array_equal(got[5], base[5]) and np.array_equal(got[6], base[6]), label
 
 
+@pytest.mark.parametrize("n,k,m,m_r", [(200, 20, 40, 210), (130, 70, 9, 37), (257, 3, 5, 301)], ids=["n200", "n130_k70_short_J", "n257_odd"])
+def test_large_generic_path_takes_every_layout_of_J(n, k, m, m_r):
+    """Beyond the LDS-resident range (H in the workgroup's global workspace) J^T J runs on the matrix cores over 128-wide super-blocks whose
+    columns are staged through LDS by batched loads -- one code path for row-major J and one for column-major J / a leading dimension.  Every
+    layout must give the oracle's step, and the same step as the packed layout (the staged values are the same: identical arithmetic).
+    Shapes: a second super-block with a ragged width (n = 200, 257), fewer rows of J than one staging chunk, a row count that is not a
+    multiple of the four rows one MFMA consumes, a last column panel narrower than the others."""
+    rng = np.random.default_rng(n + 3 * m_r)
+    B = 3
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n)); sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1); mu = np.full(B, 0.05)
+    lam = 1e-3 if m_r >= n else 0.5      # (fewer rows than variables: J^T J alone is singular)
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, J=J, r=r, lam=lam, A_eq=A, b_eq=b, cons_var=cv, cons_a=ca, cons_b=cb,
+                                                            vars_=vars_, mu=mu)
+    assert np.all(ref_status == 0)
+    base = None
+    for label, Jt, kw in _layouts_of(J):
+        prob = Q.BatchedQP(n=n, k=k, m=m, J=Jt, r=T(r), lam=lam, A_eq=T(A), b_eq=T(b), cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb), **kw)
+        s = Q.QPInteriorPointSolver(prob)
+        assert s.step_kernel() == "generic", (label, s.step_kernel())
+        s.SetVariables(T(vars_))
+        delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+        assert torch.all(status == 0), label
+        assert rel_inf_rows(delta.cpu().numpy(), ref).max() < 1e-10, label
+        np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, atol=1e-9, err_msg=label)
+        G, c, half = Q.linearize(prob, force_generic=True)
+        got = (delta.cpu().numpy().copy(), np.tril(G.cpu().numpy().transpose(0, 2, 1)), c.cpu().numpy().copy())
+        if base is None:
+            Gref = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)
+            np.testing.assert_allclose(got[1], np.tril(Gref), rtol=0, atol=1e-11 * m_r)
+            np.testing.assert_allclose(got[2], np.einsum("bqi,bq->bi", J, r), rtol=0, atol=1e-11 * m_r)
+            base = got
+            continue
+        for a_, b_ in zip(got, base):
+            assert np.array_equal(a_, b_), label
+
+
 # ------------------------------------------------------------------ Params::decrease_mu_only_on_small_error (qp.hpp:154-157, qp.cc:140-146)
 @pytest.mark.parametrize("shape", [(8, 2, 4, 16), (32, 4, 16, 64), (64, 8, 32, 128), (64, 24, 32, 128), (100, 8, 30, 128)],
                          ids=["one_tile", "grid32", "grid64", "two_y_tiles", "grid128"])
