@@ -231,16 +231,33 @@ __device__ MO_INLINE void load_qp(const Ws<T>& w, int n, int k, const T* G, int 
     for (int idx = tid; idx < P * w.ldh; idx += kThreads) w.H[idx] = (T)0;
   }
   __syncthreads();
+  // Copies into H go in groups of eight loads followed by eight stores: with H in a global workspace the compiler must assume that a store to H
+  // may alias the next load, and a load-store-load-store chain exposes one memory latency per element.
   if (G) {
-    for (int j = 0; j < n; ++j)
-      for (int i = j + tid; i < n; i += kThreads) w.H[i + (size_t)j * w.ldh] = G[i + (size_t)j * G_ld];
+    for (int j0 = 0; j0 < n; j0 += 8)
+      for (int i = j0 + tid; i < n; i += kThreads) {
+        T v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (j0 + e < n && i >= j0 + e) ? G[i + (size_t)(j0 + e) * G_ld] : (T)0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (j0 + e < n && i >= j0 + e) w.H[i + (size_t)(j0 + e) * w.ldh] = v[e];
+      }
     for (int i = tid; i < n; i += kThreads) w.cvec[i] = c[i];
   }
   if (k > 0) {   // the k x n block of A_eq as one flat index (k is small: a loop over columns leaves most of the workgroup idle in every round trip)
-#pragma unroll 4
-    for (int idx = tid; idx < n * k; idx += kThreads) {
-      const int j = idx / k, q = idx - j * k;
-      w.H[n + q + (size_t)j * w.ldh] = A[q + (size_t)j * A_ld];
+    for (int base = 0; base < n * k; base += 8 * kThreads) {
+      T v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = base + e * kThreads + tid, j = idx / k, q = idx - j * k;
+        v[e] = idx < n * k ? A[q + (size_t)j * A_ld] : (T)0;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = base + e * kThreads + tid, j = idx / k, q = idx - j * k;
+        if (idx < n * k) w.H[n + q + (size_t)j * w.ldh] = v[e];
+      }
     }
   }
   for (int q = tid; q < k; q += kThreads) w.beq[q] = b[q];
@@ -1122,8 +1139,15 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
       if (MODE == MODE_LINEARIZE || MODE == MODE_SOLVE) {
         // LINEARIZE output, or the per-problem G scratch the Solve loop reloads after each factorisation
         T* Go = (T*)a.G_out + p * a.G_out_stride;
-        for (int j = 0; j < n; ++j)
-          for (int i = tid; i < n; i += kThreads) Go[i + (size_t)j * a.G_out_ld] = i >= j ? w.H[i + (size_t)j * w.ldh] : (T)0;
+        for (int j0 = 0; j0 < n; j0 += 8)                      // (eight loads, then eight stores: see load_qp)
+          for (int i = tid; i < n; i += kThreads) {
+            T v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (j0 + e < n && i >= j0 + e) ? w.H[i + (size_t)(j0 + e) * w.ldh] : (T)0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (j0 + e < n) Go[i + (size_t)(j0 + e) * a.G_out_ld] = v[e];
+          }
         T* co = (T*)a.c_out + p * a.c_out_stride;
         for (int i = tid; i < n; i += kThreads) co[i] = w.cvec[i];
         if (a.half_sq_out && tid == 0) ((T*)a.half_sq_out)[p * (a.half_sq_stride ? a.half_sq_stride : 1)] = w.red[8];
