@@ -720,13 +720,14 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
   int status = MO_STATUS_OK;
   for (int kb = 0; kb < P && status == MO_STATUS_OK; kb += NB) {
     const int wd = P - kb < NB ? P - kb : NB, rows = P - kb, ldp = rows | 1;
-    if (kThreads == 256 && rows <= 512 && NB <= 32) {                            // the panel in registers (uniform)
+    if (kThreads == 256 && NB <= 32 && rows <= (NB <= 16 ? 512 : 256)) {         // the panel in registers (uniform)
+      // (one or two rows per thread with 16 columns, one with 32: 32-column panels of more than 256 rows only exist for 256 < n + k <~ 280 with
+      // few constraints, and every further instantiation costs the others registers -- four rows per thread made n = 256 10 % slower)
       if (NB <= 16) {
         if (rows <= 256) status = factor_panel_regs<T, 16, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
         else status = factor_panel_regs<T, 16, 2>(w, panel, kb, wd, rows, ldp, tid, found_zero);
       } else {
-        if (rows <= 256) status = factor_panel_regs<T, 32, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
-        else status = factor_panel_regs<T, 32, 2>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+        status = factor_panel_regs<T, 32, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
       }
       if (status != MO_STATUS_OK) break;                                         // uniform
       __syncthreads();                                                           // the LDS copy of the panel is read by other threads below
