@@ -1150,8 +1150,13 @@ def test_large_fp64_plan_runs_on_both_kernel_families():
 
 
 @pytest.mark.parametrize("n,k,m,m_r,level,dt", [(256, 40, 128, 300, "J", torch.float64), (256, 40, 128, 0, "QP", torch.float64), (200, 0, 30, 210, "J", torch.float64),
-                                                (160, 50, 0, 170, "J", torch.float64), (300, 20, 64, 310, "J", torch.float32), (130, 70, 17, 0, "QP", torch.float64)],
-                         ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP"])
+                                                (160, 50, 0, 170, "J", torch.float64), (300, 20, 64, 310, "J", torch.float32), (130, 70, 17, 0, "QP", torch.float64),
+                                                # shapes at the edges of the matrix-core J^T J / register-panel code (round 3): three rows of J (less than the four one
+                                                # MFMA consumes), n + k just beyond 192, three full 128-wide super-blocks with two rows per thread in the panel, a first
+                                                # panel of more than 512 rows (LDS panel path) followed by register panels, fp32 with a ragged second super-block
+                                                (145, 0, 0, 3, "J", torch.float64), (190, 3, 2, 193, "J", torch.float64), (384, 16, 32, 390, "J", torch.float64),
+                                                (520, 8, 16, 64, "J", torch.float64), (260, 0, 10, 270, "J", torch.float32)],
+                         ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP", "n145_three_rows", "n190_k3", "n384", "n520_short_J", "n260_f32"])
 def test_sizes_beyond_every_lds_resident_kernel(n, k, m, m_r, level, dt):
     """The reference resizes its solver to any N, K (qp.cc:36-48).  Beyond the fused kernels (n <= 128, k <= 31) and the LDS-resident generic
     kernel (n + k <= 192, H in LDS) the generic kernel keeps H in a global workspace of its workgroup: blocked right-looking LDL^T (column
