@@ -333,6 +333,7 @@ __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, cons
       const int wj = diag ? 0 : SBW, wc = wi + wj;          // (J0 < I0: a full block of columns)
       const int ws = large_jtj_stride(wc);
       int CR = (w.region / (ws + 1)) & ~3;
+      if (CR < 4) return;                                  // (cannot happen: generic_large_lds_bytes refuses a region below four staged rows -- but never loop on a zero step)
       if (CR > ((m_r + 3) & ~3)) CR = (m_r + 3) & ~3;
       T* const rcs = w.Jc + (size_t)CR * ws;               // r of the staged rows
       // which of the wave's TQ x TQ tiles exist (wave-uniform): inside the block's columns, and on / below the diagonal of a diagonal block
@@ -1592,7 +1593,10 @@ size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
 // fits the 160 KiB of a CU; everything beyond runs with H in a global workspace (LARGE).
 bool generic_needs_large(const KernelArgs& a, int elem_size) { return a.n + a.k > 192 || generic_lds_bytes(a, elem_size) > 160 * 1024; }
 size_t generic_large_lds_bytes(const KernelArgs& a, int elem_size) {
-  if (panel_cols_for(a.n, a.k, a.m, a.m_r, elem_size) == 0) return (size_t)1 << 30;   // not even the vectors and an 8-column panel fit
+  const int nb_cols = panel_cols_for(a.n, a.k, a.m, a.m_r, elem_size);
+  if (nb_cols == 0) return (size_t)1 << 30;   // not even the vectors and an 8-column panel fit
+  // the J^T J staging needs four rows of its widest super-block (two 128-column blocks, stride 272, + r) in the panel region
+  if (a.m_r > 0 && (size_t)((a.n + a.k) | 1) * nb_cols < 4 * (size_t)(large_jtj_stride(a.n < 256 ? a.n : 256) + 1)) return (size_t)1 << 30;
   const size_t e = elem_size == 8 ? ws_elems_large<double>(a.n, a.k, a.m, a.m_r) : ws_elems_large<float>(a.n, a.k, a.m, a.m_r);
   return (e * elem_size + (size_t)(a.m + 8) * sizeof(int) + 15) & ~(size_t)15;
 }
