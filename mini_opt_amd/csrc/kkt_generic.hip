@@ -319,6 +319,9 @@ __host__ __device__ inline int large_jtj_stride(int wc) { return wc + 16 + ((32 
 #ifndef MO_LARGE_TQ
 #define MO_LARGE_TQ 4
 #endif
+#ifndef MO_LARGE_TW
+#define MO_LARGE_TW 8   // 16 x 16 tiles of the trailing update a wave handles per round (its row strip x 16 MO_LARGE_TW columns)
+#endif
 template <typename T>
 __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r, int tid) {
   typedef Mfma16<T> MF;
@@ -779,13 +782,13 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
         const int ib = I0 + 16 * wv;                                             // first row of this wave's tiles
         if (ib >= tr) continue;                                                  // (wave-uniform; no barrier inside these loops)
         const int i = ib + l, irow = wd + (i < tr ? i : tr - 1);
-        for (int J0 = 0; J0 <= I0; J0 += 64) {
-          bool need[4];
-          int jrow[4];
-          Acc acc[4];
-          T hv[4][4];
+        for (int J0 = 0; J0 <= I0; J0 += 16 * MO_LARGE_TW) {   // MO_LARGE_TW tiles = one round of workspace latency
+          bool need[MO_LARGE_TW];
+          int jrow[MO_LARGE_TW];
+          Acc acc[MO_LARGE_TW];
+          T hv[MO_LARGE_TW][4];
 #pragma unroll
-          for (int b_ = 0; b_ < 4; ++b_) {
+          for (int b_ = 0; b_ < MO_LARGE_TW; ++b_) {
             need[b_] = J0 + 16 * b_ < tr && J0 + 16 * b_ <= ib;                  // exists, and not strictly above the diagonal
             const int jl = J0 + 16 * b_ + l;
             jrow[b_] = wd + (jl < tr ? jl : tr - 1);
@@ -802,14 +805,14 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
             const T inv = valid ? w.invd[kb + kq] : (T)0;
             const T bi = valid ? panel[irow + (size_t)kq * ldp] : (T)0;
 #pragma unroll
-            for (int b_ = 0; b_ < 4; ++b_) {
+            for (int b_ = 0; b_ < MO_LARGE_TW; ++b_) {
               if (!need[b_]) continue;
               const T aj = valid ? panel[jrow[b_] + (size_t)kq * ldp] * inv : (T)0;
               acc[b_] = MF::mac(aj, bi, acc[b_]);
             }
           }
 #pragma unroll
-          for (int b_ = 0; b_ < 4; ++b_) {
+          for (int b_ = 0; b_ < MO_LARGE_TW; ++b_) {
             if (!need[b_]) continue;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
