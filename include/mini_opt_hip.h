@@ -44,7 +44,7 @@ extern "C" {
 #define MO_OK 0
 #define MO_ERR_INVALID_ARGUMENT (-1) /* null pointer, bad enum, bad params (CheckParams qp.cc:76-82) */
 #define MO_ERR_DIMENSION (-2)        /* dimension mismatch (Setup asserts, qp.cc:24-34) */
-#define MO_ERR_UNSUPPORTED (-3)      /* problem too large for the LDS-resident kernels, unknown dtype ... */
+#define MO_ERR_UNSUPPORTED (-3)      /* unknown dtype; state / residual vectors of one problem beyond the 160 KiB of LDS (n in the thousands) ... */
 #define MO_ERR_HIP (-4)              /* a HIP runtime call failed; see mo_last_error() */
 #define MO_ERR_NO_DEVICE (-5)        /* no usable gfx950 device: the HIP path never falls back to the CPU */
 
