@@ -67,6 +67,11 @@ typedef enum { MO_SATISFIED_KKT_TOL = 0, MO_MAX_ITERATIONS = 1 } mo_termination;
 /* plan flags */
 #define MO_PLAN_FORCE_GENERIC 1u /* always use the shape-generic LDS kernel (testing / A-B measurements) */
 #define MO_PLAN_NO_TINY 2u       /* do not use the one-tile kernels for n + k <= 15 (testing / A-B: the 32-variable tile grid instead) */
+/* How the fused kernels hand out problems to the waves of their persistent grid.  Default: launches of a few problems per wave are split
+ * statically, larger ones take tickets from a device counter in guided chunks.  The two flags pin one scheme for every launch of the plan
+ * (testing: the suite's small batches would otherwise never take a ticket). */
+#define MO_PLAN_TICKETS_ALWAYS 4u
+#define MO_PLAN_STATIC_ROUNDS_ALWAYS 8u
 
 typedef struct {
   int32_t n;   /* variables (QPInteriorPointSolver::dims_.N, qp.cc:37) */
@@ -77,7 +82,9 @@ typedef struct {
   int32_t device; /* HIP device ordinal */
   uint32_t flags; /* MO_PLAN_* */
   int32_t reserved;
-  int64_t max_batch; /* sizes plan-owned scratch (only mo_qp_solve with J-level input needs any) */
+  int64_t max_batch; /* sizes plan-owned scratch: the (G, c) of mo_qp_solve with J-level input on the generic kernel; beyond the
+                        LDS-resident range (n + k > 192, or the system exceeds 160 KiB of LDS) also the number of H workspaces
+                        mo_plan_create allocates (0: one per workgroup of the full persistent grid) */
 } mo_plan_desc;
 
 typedef struct mo_plan mo_plan; /* opaque; replaces the solver-owned scratch of qp.hpp:221-231 */

@@ -17,6 +17,11 @@ MO_F64, MO_F32 = 0, 1
 MO_COL_MAJOR, MO_ROW_MAJOR = 0, 1
 MO_PLAN_FORCE_GENERIC = 1
 MO_PLAN_NO_TINY = 2
+MO_PLAN_TICKETS_ALWAYS = 4
+MO_PLAN_STATIC_ROUNDS_ALWAYS = 8
+# Plan flags OR-ed into every plan the Python mirror creates (tests/test_gpu_ticket_path.py re-runs the parity tests under each scheduling
+# scheme this way).  A knob of THIS mirror: the library itself reads no environment variable.
+EXTRA_PLAN_FLAGS = int(os.environ.get("MO_PLAN_EXTRA_FLAGS", "0"), 0)
 MO_STEP_NO_INEQUALITIES = 1
 (MO_STATUS_OK, MO_STATUS_NONPOSITIVE_SLACK, MO_STATUS_FACTORIZATION_FAILED, MO_STATUS_NONFINITE, MO_STATUS_BAD_INDEX,
  MO_STATUS_NOT_POSITIVE_DEFINITE) = range(6)

@@ -1551,7 +1551,13 @@ template <int NT, int WPS, int MC = 1, int NY = 1> struct SolveCfg {
   static constexpr int NH = NT / 2;
   static constexpr int SLOT = NH * 1024 + 64;
   static constexpr int MCAP = 64 * MC;                    // constraint slots: MC per lane
-  static constexpr int VEC = (6 * N + 32 * NY) * 8;       // xs, xp, azS, diagS, rhoS, tmp, ysmall[32 NY]
+  // CLDS: the constraint data (s, z, a, b, variable) live in LDS between the phases of a pass instead of in 9 MC registers across the
+  // factorisation.  On where the tiles alone take most of the budget: two y tiles on the 64 grid are 21 tiles = 168 of the 256 registers
+  // of two waves per SIMD (round 3: 308 - 408 B of scratch per lane, 4.4 x the algorithmic HBM traffic).  The price is LDS: 36 MCAP bytes
+  // less for parked tiles (one or two more of them in the L2-resident global scratch).
+  static constexpr bool CLDS = NY >= 2 && WPS >= 2;
+  static constexpr int CONS = CLDS ? MCAP * 36 : 0;       // cS, cZ, cA, cB (doubles), cV (int)
+  static constexpr int VEC = (6 * N + 32 * NY) * 8 + CONS;  // xs, xp, azS, diagS, rhoS, tmp, ysmall[32 NY] (+ the constraint arrays)
   static constexpr int D_FIT = ((160 * 1024) / (4 * WPS) - VEC) / SLOT;
   static constexpr int D_TUNED = NT > 4 ? 4 : (NT == 4 ? (WPS >= 3 ? 4 : 6) : 8);
   static constexpr int D = MC == 1 ? D_TUNED : (D_FIT > 8 ? 8 : D_FIT);
@@ -1589,9 +1595,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
   double* const rhoS = diagS + N;                                 // inequality part of r_aug per variable
   double* const tmp = rhoS + N;                                   // layout-conversion scratch (R <-> V16, natural <-> permuted)
   double* const ysm = tmp + N;                                    // [0, YN): y ; [YN, 2 YN): -r_pe
+  constexpr bool CLDS = C::CLDS;
+  constexpr int MCAP = C::MCAP;
+  double* const cS = ysm + 2 * YN;                                // CLDS: s, z, a, b, variable of constraint ix at index ix (see SolveCfg)
+  double* const cZ = cS + MCAP;
+  double* const cA = cZ + MCAP;
+  double* const cB = cA + MCAP;
+  int* const cV = reinterpret_cast<int*>(cB + MCAP);
   const unsigned ring_base = (unsigned)(uintptr_t)smem;
 
-  const double inv_m = a.m > 0 ? 1.0 / (double)a.m : 0.0;   // (k, m, n, m_r are read per problem / per pass, see below)
+  // 1 / M for ComputeMu (qp.cc:509-516): one f64 division per kernel; the quotient is wave-uniform and is moved to a scalar register pair
+  // (as a VGPR pair it was spilled and reloaded twice per pass)
+  double inv_m = a.m > 0 ? 1.0 / (double)a.m : 0.0;   // (k, m, n, m_r are read per problem / per pass, see below)
+  inv_m = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(inv_m)), __builtin_amdgcn_readfirstlane(__double2loint(inv_m)));
   for (int i = (int)(threadIdx.x & 63); i < D * SLOT / 8; i += 64) reinterpret_cast<double*>(smem)[i] = 0.0;
   lds_fence();
 
@@ -1664,30 +1680,75 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         cb[ci] = ((const double*)ka->cons_b)[p * ka->cons_stride + ix];
       }
     }
-    double b_col[NY];
-#pragma unroll
-    for (int q = 0; q < NY; ++q) b_col[q] = (16 * q + j < k) ? ((const double*)ka->b + p * ka->b_stride)[16 * q + j] : 0.0;
     const double* const Ap = k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr;
-
-    // ---- state: x in the permuted V16 layout (position 16c + j, replicated over g), y in lanes j < k, s / z per constraint lane
-    double xv[NT], yv[NY], cs[MC], cz[MC];  // yv[q]: equality row 16 q + j
-#pragma unroll
-    for (int q = 0; q < NY; ++q) yv[q] = 0.0;
-#pragma unroll
-    for (int c = 0; c < NT; ++c) xv[c] = 0.0;
+    // CLDS: every phase that computes with the constraint data fetches its registers from LDS first (all of them are overwritten, so
+    // nothing of them is live across the factorisation or the corrector's second solve) and writes s / z back when it changed them.
+    double cs[MC], cz[MC];
 #pragma unroll
     for (int ci = 0; ci < MC; ++ci) { cs[ci] = 1.0; cz[ci] = 1.0; }
+    auto cons_load = [&](int lane) {
+      if constexpr (CLDS) {
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          const int ix = lane + 64 * ci;
+          cvar[ci] = cV[ix]; ca[ci] = cA[ix]; cb[ci] = cB[ix]; cs[ci] = cS[ix]; cz[ci] = cZ[ix];
+        }
+      }
+    };
+    auto cons_store_state = [&](int lane) {
+      if constexpr (CLDS) {
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) { cS[lane + 64 * ci] = cs[ci]; cZ[lane + 64 * ci] = cz[ci]; }
+      }
+    };
+    auto cons_store_all = [&](int lane) {
+      if constexpr (CLDS) {
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) { cV[lane + 64 * ci] = cvar[ci]; cA[lane + 64 * ci] = ca[ci]; cB[lane + 64 * ci] = cb[ci]; }
+        cons_store_state(lane);
+      }
+    };
+
+    // ---- state.  x and y LIVE IN LDS (xs: natural order, xp: permuted position order, ysm[0, YN): y, zero beyond k) -- at the top of every
+    // pass and at every exit of the pass loop the LDS copies are the current iterate; registers hold them only while a phase computes with
+    // them.  (Round 3 carried x, y, the residual r_d / r_pe, r_pi / r_comp and six record scalars in VGPRs across the factorisation: with the
+    // 120 tile registers that was 136 B of scratch per lane at the 256-register budget of two waves per SIMD, and the spill traffic
+    // competed with the parked tiles for L2.)  s / z stay in registers, one slot per constraint lane -- unless CLDS.
+    // (the lane coordinates are arguments: a pass uses its own opaque copies, nothing lane-derived may stay live across a factorisation)
+    auto publish_x = [&](const double (&xq)[NT], int g, int j) {   // all lanes hold the V16 copy (replicated over g); row 0 writes both orders
+      if (g == 0) {
+        stv<NT, QPL>(xs, j, xq);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xp[16 * c + j] = xq[c];
+      }
+    };
+    auto publish_y = [&](const double (&yq)[NY], int g, int j) {
+      if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < NY; ++q) ysm[16 * q + j] = (16 * q + j < k) ? yq[q] : 0.0;
+      }
+    };
     // MODE_RESIDUAL: EvaluateKKTConditions + ComputeErrors (qp.cc:391-437) on the caller's state -- part A of a pass, then the outputs
     const bool residual_mode = ka->mode == MODE_RESIDUAL;
     const bool iterate_mode = ka->mode == MODE_ITERATE || residual_mode;  // one Iterate (qp.cc:153-201) on the caller's state and mu
-    if (iterate_mode || ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
-      ldv_n<NT, QPL>(vp, j, nn, xv);
+    {
+      double xq[NT], yq[NY];
 #pragma unroll
-      for (int q = 0; q < NY; ++q)
-        if (16 * q + j < k) yv[q] = vp[nn + m + 16 * q + j];
+      for (int q = 0; q < NY; ++q) yq[q] = 0.0;
 #pragma unroll
-      for (int ci = 0; ci < MC; ++ci)
-        if (lane + 64 * ci < m) { cs[ci] = vp[nn + lane + 64 * ci]; cz[ci] = vp[nn + m + k + lane + 64 * ci]; }
+      for (int c = 0; c < NT; ++c) xq[c] = 0.0;
+      if (iterate_mode || ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+        ldv_n<NT, QPL>(vp, j, nn, xq);
+#pragma unroll
+        for (int q = 0; q < NY; ++q)
+          if (16 * q + j < k) yq[q] = vp[nn + m + 16 * q + j];
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci)
+          if (lane + 64 * ci < m) { cs[ci] = vp[nn + lane + 64 * ci]; cz[ci] = vp[nn + m + k + lane + 64 * ci]; }
+      }
+      publish_x(xq, g, j);
+      publish_y(yq, g, j);
+      lds_fence();
     }
     bool lane_bad_index = false;
 #pragma unroll
@@ -1697,6 +1758,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci) cvar[ci] = 0;
     }
+    cons_store_all(lane);
 
     int st = bad_index ? MO_STATUS_BAD_INDEX : MO_STATUS_OK;
     int term = MO_MAX_ITERATIONS, it = 0;
@@ -1705,9 +1767,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     double* iter_out = ka->iterations ? (double*)ka->iterations + (size_t)p * ka->sp.max_iterations * MO_ITER_RECORD : nullptr;
 
     // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
-    auto clamp_and_init_slacks = [&]() {
-      if (g == 0) stv<NT, QPL>(xs, j, xv);
-      lds_fence();
+    auto clamp_and_init_slacks = [&](int lane, int g, int j) {   // on the x that xs holds; leaves the clamped x in xs and xp
+      cons_load(lane);
       for (int c = 0; c < m; ++c) {  // wave-uniform loop; one constraint at a time keeps the reference's order
 #pragma unroll
         for (int ci = 0; ci < MC; ++ci) {
@@ -1721,7 +1782,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
         lds_fence();
       }
-      ldv<NT, QPL>(xs, j, xv);
+      {
+        double xq[NT];
+        ldv<NT, QPL>(xs, j, xq);
+        if (g == 0) {
+#pragma unroll
+          for (int c = 0; c < NT; ++c) xp[16 * c + j] = xq[c];
+        }
+      }
       double sz = 0.0;
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci) {
@@ -1732,12 +1800,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           sz += cs[ci] * cz[ci];
         }
       }
+      cons_store_state(lane);
       if (ka->sp.initialize_mu_with_complementarity) {  // qp.cc:115
         const double t = wave_sum_f64(sz);
         mu = t * inv_m;
       }
     };
-    if (st == MO_STATUS_OK && !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks();
+    if (st == MO_STATUS_OK && !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_NAIVE) clamp_and_init_slacks(lane, g, j);
     if (!iterate_mode && ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED && ka->sp.initialize_mu_with_complementarity) {
       double sz = 0.0;  // qp.cc:115 on the caller's state: mu = s^T z / M (0 without inequalities, qp.cc:509-516)
 #pragma unroll
@@ -1775,11 +1844,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       lds_fence();
     }
     double mu_used = mu;   // the mu handed to the previous Iterate
-    double ip_alpha_p = 1.0, ip_alpha_d = 1.0;
     // Mehrotra predictor-corrector (qp.cc:170-187): solve with mu = 0, probe alpha(tau = 1), then solve again with the second-order
     // term ds_aff dz_aff and mu = sigma mu_input on the right-hand side -- through the factors of the first solve (solve_second_rhs).
     const bool use_pc = (iterate_mode ? ka->barrier_strategy : ka->sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
-    double ip_mu = mu, probe_p = __builtin_nan(""), probe_d = __builtin_nan(""), mu_aff = __builtin_nan(""), mu_pc = 0.0;
 
     while (st == MO_STATUS_OK) {
       const bool include_ineq = !guess_pass && !(residual_mode && (ka->flags & MO_STEP_NO_INEQUALITIES));
@@ -1800,14 +1867,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
       load_a_tiles<NT, QPL, NY>(Ap, ka->A_ld, k, nn, g, j, U);
-      // publish the state for the layout conversions below; zero the per-variable scatter arrays
-      if (g == 0) {
-        stv<NT, QPL>(xs, j, xv);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) xp[16 * c + j] = xv[c];
-#pragma unroll
-        for (int q = 0; q < NY; ++q) ysm[16 * q + j] = (16 * q + j < k) ? yv[q] : 0.0;
-      }
+      // (xs / xp / ysm hold the state, see above); zero the per-variable scatter arrays
       if (lane < N / 2) {
         azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0;
         diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
@@ -1867,13 +1927,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       lds_fence();
+      cons_load(lane);
       double r_pi[MC], r_comp[MC];
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci) {
         r_pi[ci] = 0.0; r_comp[ci] = 0.0;
         if (include_ineq && lane + 64 * ci < m) {
           atomicAdd(&azS[cvar[ci]], ca[ci] * cz[ci]);                    // qp.cc:415
-          r_pi[ci] = ca[ci] * xs[cvar[ci]] + cb[ci] - cs[ci];            // qp.cc:416
+          r_pi[ci] = fma(ca[ci], xs[cvar[ci]], cb[ci]) - cs[ci];         // qp.cc:416
           r_comp[ci] = cs[ci] * cz[ci];                                  // qp.cc:417
         }
       }
@@ -1881,6 +1942,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       {
       // w = K [x; -y] as tile products: type 1 (sum over tile rows, result on lanes) over every stored tile,
       // type 2 (sum over tile columns, result on rows) over the strictly upper tiles; the latter goes through LDS once.
+      double xv[NT], yv[NY];   // V16 copies of the state for the type-2 products (yv is zero on lanes beyond k)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) xv[c] = xp[16 * c + j];
+#pragma unroll
+      for (int q = 0; q < NY; ++q) yv[q] = ysm[16 * q + j];
       double acc1[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc1[b] = 0.0;
@@ -1913,8 +1979,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
         for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
       }
+      {
+        const double* const bp = (const double*)ka->b + p * ka->b_stride;
 #pragma unroll
-      for (int q = 0; q < NY; ++q) r_pe[q] = (16 * q + j < k) ? cross_row_sum(acc1[NT + q]) + b_col[q] : 0.0;  // qp.cc:408
+        for (int q = 0; q < NY; ++q) r_pe[q] = (16 * q + j < k) ? cross_row_sum(acc1[NT + q]) + bp[16 * q + j] : 0.0;  // qp.cc:408
+      }
       {
         double t = 0.0;
 #pragma unroll
@@ -1963,10 +2032,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           const double cur_mu = n_rc1 * inv_m;                      // ComputeMu, qp.cc:509-516 (one f64 division per kernel, not per pass)
           double kmax2 = kf[0];                                     // KKTError::Max() squared
           kmax2 = kf[1] > kmax2 ? kf[1] : kmax2; kmax2 = kf[2] > kmax2 ? kf[2] : kmax2; kmax2 = kf[3] > kmax2 ? kf[3] : kmax2;
-          if (kmax2 < ka->sp.termination_kkt_tol * ka->sp.termination_kkt_tol && cur_mu < ka->sp.termination_complementarity_tol) {  // qp.cc:132-137
+          // The operands are wave-uniform VALUES in vector registers; __any() turns each verdict into a scalar condition, so that the exits of
+          // the pass loop are scalar branches and `it`, `term`, `st` and the loop's flags live in SGPRs (as divergent branches they cost an
+          // EXEC-mask pair each and turned every one of those into a VGPR).
+          if (__any(kmax2 < ka->sp.termination_kkt_tol * ka->sp.termination_kkt_tol && cur_mu < ka->sp.termination_complementarity_tol)) {  // qp.cc:132-137
             term = MO_SATISFIED_KKT_TOL;
             stop = true;
-          } else if (kmax2 <= mu * mu || !ka->sp.decrease_mu_only_on_small_error) {               // qp.cc:140-146 (mu > 0)
+          } else if (__any(kmax2 <= mu * mu) || !ka->sp.decrease_mu_only_on_small_error) {        // qp.cc:140-146 (mu > 0)
             if (ka->sp.barrier_strategy == MO_FIXED_DECREASE) mu *= ka->sp.sigma;
             else mu = ka->sp.sigma * cur_mu;
           }
@@ -1983,11 +2055,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           const double rt = sqrt(sq);
           if (have_prev && lane < 4) iter_out[(size_t)(it - 1) * MO_ITER_RECORD + 4 + lane] = rt;
           if (!stop && lane >= 4 && lane < 8) iter_out[(size_t)it * MO_ITER_RECORD + (lane - 4)] = rt;
-          if (have_prev && lane == 0) {
-            double* rec = iter_out + (size_t)(it - 1) * MO_ITER_RECORD;
-            rec[8] = ip_mu; rec[9] = ip_alpha_p; rec[10] = ip_alpha_d;
-            rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
-          }
+          // (IPIterationOutputs of iteration it - 1 -- mu, alpha, alpha_probe, mu_affine -- were written when that iteration ended)
         }
         if (stop) break;
       }
@@ -2026,6 +2094,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
           for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? dd[c] : 0.0;
           if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[c]);          // -r_aug, position order (qp.cc:337-342)
+          if (g == 0) azS[16 * c + j] = r_d[c];                     // r_d for the corrector's right-hand side (azS is dead: r_d consumed it)
         }
       }
       if (g == 0) {
@@ -2060,15 +2129,33 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       bool elim_ok;
       if constexpr (NY == 1 && (NT == 4 || NT >= MO_LA_MIN_NT)) elim_ok = block_eliminate_lookahead<NT>(U, k, g, j);
       else elim_ok = block_eliminate<NT, SW, NY>(U, k, g, j);
-      if (!elim_ok) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+      if (!__all(elim_ok)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }   // (__all: a scalar branch, see the decision point)
 #else
-      if (!block_eliminate<NT, SW, NY>(U, k, g, j)) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
+      if (!__all(block_eliminate<NT, SW, NY>(U, k, g, j))) { st = MO_STATUS_FACTORIZATION_FAILED; break; }
 #endif
       double xb[NB];
       back_substitute<NT, NY>(U, k, j, xb);  // xb[c] = dx (permuted), xb[NT + q] = -dy
       double dyv[NY], dsv[MC], dzv[MC], ap = 1.0, ad = 1.0;
 #pragma unroll
       for (int q = 0; q < NY; ++q) dyv[q] = 0.0;
+      // r_pi / r_comp (qp.cc:416-417) are recomputed behind the factorisation instead of being carried across it in registers: the same
+      // operations on the same operands (xs still holds this pass's x), hence the same bits.  The empty asm keeps hipcc from recognising
+      // the products and holding on to the first copies.
+      double r_pi2[MC], r_comp2[MC];
+      auto post_cons = [&]() {   // (CLDS: also called again behind the corrector's second solve, with the registers refetched from LDS)
+        cons_load(lane);
+#pragma unroll
+        for (int ci = 0; ci < MC; ++ci) {
+          if constexpr (!CLDS) asm volatile("" : "+v"(cs[ci]), "+v"(cz[ci]));
+          if constexpr (CLDS) cs_inv[ci] = include_ineq ? rcp_f64(cs[ci]) : 1.0;   // the same reciprocal part B computed: same bits
+          r_pi2[ci] = 0.0; r_comp2[ci] = 0.0;
+          if (!guess_pass && lane + 64 * ci < m) {
+            r_pi2[ci] = fma(ca[ci], xs[cvar[ci]], cb[ci]) - cs[ci];
+            r_comp2[ci] = cs[ci] * cz[ci];
+          }
+        }
+      };
+      post_cons();
       // From a solution xb to the direction: dy, dx (natural order in LDS), ds, dz, the step lengths (qp.cc:359-363, 485-507).
       auto finish_direction = [&](double mu_s, double tau) -> bool {
         bool finite = true;
@@ -2091,8 +2178,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         for (int ci = 0; ci < MC; ++ci) {
           dsv[ci] = 0.0; dzv[ci] = 0.0;
           if (lane + 64 * ci < m) {
-            dsv[ci] = ca[ci] * tmp[cvar[ci]] + r_pi[ci];                                               // qp.cc:361
-            dzv[ci] = -(cz[ci] * cs_inv[ci]) * dsv[ci] - cs_inv[ci] * (r_comp[ci] + aff[ci] - mu_s);   // qp.cc:362
+            dsv[ci] = ca[ci] * tmp[cvar[ci]] + r_pi2[ci];                                              // qp.cc:361
+            dzv[ci] = -(cz[ci] * cs_inv[ci]) * dsv[ci] - cs_inv[ci] * (r_comp2[ci] + aff[ci] - mu_s);  // qp.cc:362
             if (cs[ci] + dsv[ci] <= 0.0 && fabs(dsv[ci]) > 0.0) ap = fmin(ap, -tau * cs[ci] * rcp_f64(dsv[ci]));  // qp.cc:498-503
             if (cz[ci] + dzv[ci] <= 0.0 && fabs(dzv[ci]) > 0.0) ad = fmin(ad, -tau * cz[ci] * rcp_f64(dzv[ci]));
             finite = finite && (fabs(dsv[ci]) < INFINITY) && (fabs(dzv[ci]) < INFINITY);
@@ -2110,16 +2197,24 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
         for (int c = 0; c < NT; ++c) finite = finite && (fabs(xb[c]) < INFINITY);
         if (!__all(finite)) { st = MO_STATUS_NONFINITE; break; }
+        {
+          double xq[NT], yq[NY];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) xv[c] = xb[c];
+          for (int c = 0; c < NT; ++c) xq[c] = xb[c];
 #pragma unroll
-        for (int q = 0; q < NY; ++q) yv[q] = (16 * q + j < k) ? -xb[NT + q] : 0.0;
+          for (int q = 0; q < NY; ++q) yq[q] = (16 * q + j < k) ? -xb[NT + q] : 0.0;
+          publish_x(xq, g, j);
+          publish_y(yq, g, j);
+          lds_fence();
+        }
         guess_pass = false;
-        clamp_and_init_slacks();
+        clamp_and_init_slacks(lane, g, j);
+        lds_fence();
         continue;
       }
       if (!finish_direction(mu_step, predictor_pass ? 1.0 : 0.995)) { st = MO_STATUS_NONFINITE; break; }  // tau: qp.cc:174, 192
-      ip_mu = mu;                                                                      // IPIterationOutputs::mu
+      double ip_mu = mu;                                                               // IPIterationOutputs::mu
+      double probe_p = __builtin_nan(""), probe_d = __builtin_nan(""), mu_aff = __builtin_nan("");
       if (predictor_pass) {
         probe_p = ap; probe_d = ad;                                                    // alpha_probe, qp.cc:174
         double t_sdz = 0.0, t_zds = 0.0, t_dsdz = 0.0;
@@ -2137,16 +2232,20 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         ma += (ad * ap) * dsdz * inv_m;
         mu_aff = ma > 0.0 ? ma : 0.0;
         const double ratio = mu_aff * rcp_f64(mu);
-        mu_pc = (ratio * ratio * ratio) * mu;                                          // qp.cc:182-183
+        const double mu_pc = (ratio * ratio * ratio) * mu;                             // qp.cc:182-183
         // The corrector solve (qp.cc:187): same matrix, right-hand side with ds_aff dz_aff and sigma mu -- pushed through the factors
         // still sitting in the tiles instead of a second factorisation.
-        if (lane < N / 2) { rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0; }
+        {   // (a zero made on the spot: hipcc hoisted the constant pair out of the problem loop and then spilled it)
+          double z0;
+          asm volatile("v_mov_b64 %0, 0" : "=v"(z0));
+          if (lane < N / 2) { rhoS[2 * lane] = z0; rhoS[2 * lane + 1] = z0; }
+        }
         lds_fence();
 #pragma unroll
         for (int ci = 0; ci < MC; ++ci) {
           if (lane + 64 * ci < m) {
             const double zs = cz[ci] * cs_inv[ci];
-            atomicAdd(&rhoS[cvar[ci]], ca[ci] * zs * r_pi[ci] + ca[ci] * (r_comp[ci] + aff[ci] - mu_pc) * cs_inv[ci]);  // qp.cc:340-341
+            atomicAdd(&rhoS[cvar[ci]], ca[ci] * zs * r_pi2[ci] + ca[ci] * (r_comp2[ci] + aff[ci] - mu_pc) * cs_inv[ci]);  // qp.cc:340-341
           }
         }
         lds_fence();
@@ -2155,23 +2254,36 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           double rr[NT];
           ldv<NT, QPL>(rhoS, j, rr);
 #pragma unroll
-          for (int c = 0; c < NT; ++c) rb[c] = -(r_d[c] + rr[c]);
+          for (int c = 0; c < NT; ++c) rb[c] = -(azS[16 * c + j] + rr[c]);   // r_d was parked in azS (position order) by part B
 #pragma unroll
-          for (int q = 0; q < NY; ++q) rb[NT + q] = -r_pe[q];  // zero on lanes beyond k
+          for (int q = 0; q < NY; ++q) rb[NT + q] = ysm[YN + 16 * q + j];    // -r_pe, zero on lanes beyond k
         }
-        solve_second_rhs<NT, NY>(U, k, g, j, rb, diagS, xp, ysm + YN, xb);
+        solve_second_rhs<NT, NY>(U, k, g, j, rb, diagS, azS, ysm + YN, xb);  // (xp keeps x: the update below reads it)
+        if constexpr (CLDS) post_cons();
         if (!finish_direction(mu_pc, 0.995)) { st = MO_STATUS_NONFINITE; break; }
         ip_mu = mu_pc;
       }
       // x,s += alpha_p (dx,ds) ; y,z += alpha_d (dy,dz), qp.cc:196-199
+      {
+        double xq[NT], yq[NY];
 #pragma unroll
-      for (int c = 0; c < NT; ++c) xv[c] = fma(xb[c], ap, xv[c]);
+        for (int c = 0; c < NT; ++c) xq[c] = fma(xb[c], ap, xp[16 * c + j]);
 #pragma unroll
-      for (int q = 0; q < NY; ++q) yv[q] = fma(dyv[q], ad, yv[q]);
+        for (int q = 0; q < NY; ++q) yq[q] = fma(dyv[q], ad, ysm[16 * q + j]);
+        publish_x(xq, g, j);
+        publish_y(yq, g, j);
+      }
 #pragma unroll
       for (int ci = 0; ci < MC; ++ci) { cs[ci] = fma(dsv[ci], ap, cs[ci]); cz[ci] = fma(dzv[ci], ad, cz[ci]); }
-      mu_used = mu; ip_alpha_p = ap; ip_alpha_d = ad;
+      cons_store_state(lane);
+      mu_used = mu;
+      if (iter_out && lane == 0) {   // IPIterationOutputs of this iteration (structs.hpp:53-64); its KKT norms follow at the next decision point
+        double* rec = iter_out + (size_t)it * MO_ITER_RECORD;
+        rec[8] = ip_mu; rec[9] = ap; rec[10] = ad;
+        rec[11] = probe_p; rec[12] = probe_d; rec[13] = mu_aff;
+      }
       ++it;
+      lds_fence();
       if (iterate_mode) {  // outputs of Iterate: delta_ and IPIterationOutputs (structs.hpp:53-64)
         if (ka->delta) {
           double* dp = (double*)ka->delta + p * ka->delta_stride;
@@ -2194,9 +2306,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 
     // ---- outputs: state, termination, iteration count, Lagrange summary, status
     ka = fresh_args();
+    {
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15;   // fresh copies: the per-problem ones would be carried across the whole pass loop
+    double yv[NY];
+#pragma unroll
+    for (int q = 0; q < NY; ++q) yv[q] = ysm[16 * q + j];
+    cons_load(lane);
     if (!residual_mode) {  // the state is an input only there
+      for (int i = lane; i < nn; i += 64) vp[i] = xs[i];   // x, natural order
       if (g == 0) {
-        stv_n<NT, QPL>(vp, j, nn, xv);
 #pragma unroll
         for (int q = 0; q < NY; ++q)
           if (16 * q + j < k) vp[nn + m + 16 * q + j] = yv[q];
@@ -2220,6 +2338,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         ((double*)ka->lagrange)[2 * p] = k > 0 ? ymin : __builtin_nan("");
         ((double*)ka->lagrange)[2 * p + 1] = k > 0 ? yabs : __builtin_nan("");
       }
+    }
     }
     lds_fence();
     if (last_of_chunk) {
@@ -2299,14 +2418,18 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   // static rounds up to this many problems per wave (mo_kernels.h; measured): equal-cost work (step, Iterate, residual,
   // linearisation) splits statically further than a Solve, whose problems need different numbers of passes
   if (a.static_rounds < 0) a.static_rounds = a.mode == MODE_SOLVE ? (a.n > 32 ? 2 : 6) : (a.n > 32 ? 8 : 32);
-  static const int env_stagger = [] { const char* e = getenv("MO_FUSED_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
+#ifdef MO_TUNING   // (A/B builds only: the product library reads no environment variable)
+  static const int env_stagger = [] { const char* e = getenv("MO_FUSED_STAGGER"); return e ? atoi(e) : -1; }();
+  static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
+  static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
+#else
+  constexpr int env_stagger = -1, env_wps = 0, env_sw = -1;
+#endif
   // the 64-variable grid of the step kernel with J-level input (the BASELINE configs[2] / [4] shape); measured neutral elsewhere
   const bool headline_shape = a.mode == MODE_STEP && a.J && a.n > 32 && a.n <= 64;
   a.stagger = env_stagger >= 0 ? (env_stagger & 0xff) : (headline_shape ? 4 : 0);
   a.chain_prio = env_stagger >= 0 ? ((env_stagger >> 8) & 1) : (headline_shape ? 1 : 0);   // MO_FUSED_STAGGER = units + 256 * priority
-  // Waves per SIMD the kernel is register-budgeted for (tuning knob MO_FUSED_WPS; defaults picked from measurements).
-  static const int env_wps = [] { const char* e = getenv("MO_FUSED_WPS"); return e ? atoi(e) : 0; }();
-  static const int env_sw = [] { const char* e = getenv("MO_FUSED_SWEEP"); return e ? atoi(e) : -1; }();
+  // Waves per SIMD the kernel is register-budgeted for (defaults picked from measurements; MO_FUSED_WPS in -DMO_TUNING builds).
   // measured best: 3 (A/B in DESIGN.md; round 3: a fourth wave per SIMD on the 32 grid for batches of 3 072 < B <= 4 096 -- one round instead of
   // two for a third of the waves -- is 10 % SLOWER at BASELINE configs[1]: 0.136 vs 0.123 ms)
   const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);
@@ -2440,6 +2563,19 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
     return hipGetLastError();
   }
   const dim3 gd((unsigned)grid), bd(256 * wps);
+#ifndef MO_TUNING
+  // The product build carries ONE instantiation per tile grid and input level: three waves per SIMD, the lean sweep (SW = 3).  The other
+  // waves-per-SIMD / sweep flavours DESIGN.md section 8 measured and rejected are instantiated in -DMO_TUNING builds only.
+  (void)sw;
+  if (a.n > 32) {
+    if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, false>), gd, bd, 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, true>), gd, bd, 0, stream, a);
+  } else {
+    if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, false>), gd, bd, 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, true>), gd, bd, 0, stream, a);
+  }
+  return hipGetLastError();
+#else
   if (!a.J) {  // QP-level input: default flavour only
     if (a.n > 32) {
       if (wps == 3) hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, true>), gd, bd, 0, stream, a);
@@ -2474,6 +2610,7 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
 #undef MO_FUSED_BY_SW
 #undef MO_FUSED_LAUNCH
   return hipGetLastError();
+#endif  // MO_TUNING
 }
 
 #endif  // MO_FUSED_IMPL_ONLY

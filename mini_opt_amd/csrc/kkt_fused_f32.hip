@@ -1640,7 +1640,12 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
   // static rounds up to this many problems per wave (mo_kernels.h; measured): equal-cost work (step, Iterate, residual,
   // linearisation) splits statically further than a Solve, whose problems need different numbers of passes
   if (a.static_rounds < 0) a.static_rounds = a.mode == MODE_SOLVE ? (a.n > 32 ? 2 : 6) : (a.n > 32 ? 8 : 32);
-  static const int env_stagger = [] { const char* e = getenv("MO_FUSED_F32_STAGGER"); return e ? atoi(e) : -1; }();  // A/B knob
+#ifdef MO_TUNING   // (A/B builds only: the product library reads no environment variable)
+  static const int env_stagger = [] { const char* e = getenv("MO_FUSED_F32_STAGGER"); return e ? atoi(e) : -1; }();
+  static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int env_stagger = -1, env_wps = 0;
+#endif
   a.stagger = env_stagger >= 0 ? env_stagger : 0;
   // The work counter is zeroed on the stream in front of the kernel -- unless the launch is certain to run in static rounds, which never touch
   // it: every kernel below has at least 4 waves per workgroup and min(CUs, ceil(batch / 4)) workgroups, so batch <= rounds x 4 x workgroups
@@ -1654,7 +1659,6 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
       if (e != hipSuccess) return e;
     }
   }
-  static const int env_wps = [] { const char* e = getenv("MO_FUSED_F32_WPS"); return e ? atoi(e) : 0; }();  // tuning knob
   if (a.mode == MODE_LINEARIZE) {
     long long grid = num_cus;   // (two waves per SIMD at n = 128, three at n = 64)
     const long long need = (a.batch + 3) / 4;
@@ -1673,6 +1677,7 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
     else { if (a.n == 64) hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 3, false>), dim3((unsigned)grid), dim3(768), 0, stream, a); else hipLaunchKernelGGL((kkt_fused_f32_solve_kernel<4, 3, true>), dim3((unsigned)grid), dim3(768), 0, stream, a); }
     return hipGetLastError();
   }
+#ifdef MO_TUNING
   if (a.n > 64 && env_wps == 1) {
     constexpr int WPS = 1;
     long long grid = num_cus;
@@ -1681,7 +1686,11 @@ hipError_t launch_fused_f32(const KernelArgs& a_in, int num_cus, hipStream_t str
     if (grid < 1) grid = 1;
     if (a.n == 128) hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, false>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
     else hipLaunchKernelGGL((kkt_fused_f32_kernel<8, WPS, true>), dim3((unsigned)grid), dim3(256 * WPS), 0, stream, a);
-  } else if (a.n > 64) {
+  } else
+#else
+  (void)env_wps;
+#endif
+  if (a.n > 64) {
     constexpr int WPS = 2;  // 255 VGPRs, no scratch: the 216 accumulator registers + operands just fit two waves per SIMD
     long long grid = num_cus;
     const long long need = (a.batch + 3) / 4;

@@ -12,7 +12,11 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
   const int grid_tile = a.n > 96 ? 8 : a.n > 64 ? 6 : a.n > 32 ? 4 : 2;
   // Solve on the 64 grid: 21 live tiles + the loop state do not fit the 256 registers of two waves per SIMD (408 B of spill per lane, which
   // showed up as 30 GB of HBM traffic per launch in profiles/r03_solve_k24_*).  A/B knob MO_NY2_SOLVE_WPS=1: one wave per SIMD, no spill.
+#ifdef MO_TUNING
   static const int env_solve_wps = [] { const char* e = getenv("MO_NY2_SOLVE_WPS"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int env_solve_wps = 0;
+#endif
   const bool solve64_one_wave = solve && grid_tile == 4 && env_solve_wps == 1;
   const int wps = grid_tile == 2 ? 3 : grid_tile == 4 ? (solve64_one_wave ? 1 : 2) : 1;
   const bool one_slot = a.m <= 64;   // one constraint slot per lane is enough: fewer live registers
@@ -33,8 +37,11 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
     switch (grid_tile) {
       case 2: MO_NY2(kkt_fused_solve_kernel, 2, 3, 2); break;
       case 4:
+#ifdef MO_TUNING
         if (solve64_one_wave) { if (one_slot) MO_NY2(kkt_fused_solve_kernel, 4, 1, 1); else MO_NY2(kkt_fused_solve_kernel, 4, 1, 2); }
-        else if (one_slot) MO_NY2(kkt_fused_solve_kernel, 4, 2, 1);
+        else
+#endif
+        if (one_slot) MO_NY2(kkt_fused_solve_kernel, 4, 2, 1);
         else MO_NY2(kkt_fused_solve_kernel, 4, 2, 2);
         break;
       case 6: MO_NY2(kkt_fused_solve_kernel, 6, 1, 1); break;

@@ -1618,6 +1618,7 @@ static hipError_t launch_generic_large(const KernelArgs& a, int dtype, int num_c
   if (lds > 160 * 1024 || !a.H_work) return hipErrorInvalidValue;
   long long grid = generic_large_grid(a, elem, num_cus);
   if (grid > a.batch) grid = a.batch;
+  if (a.H_work_slots > 0 && grid > a.H_work_slots) grid = a.H_work_slots;   // one workspace per workgroup; the kernel strides over the batch
   if (grid < 1) grid = 1;
   hipError_t e = hipSuccess;
 #define MO_LAUNCH_LARGE(TYPE, MODE_)                                                                                                     \
@@ -1645,7 +1646,11 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
   const int elem = dtype == MO_F64 ? 8 : 4;
   if (generic_needs_large(a, elem)) return launch_generic_large(a, dtype, num_cus, stream);
   const size_t lds = generic_lds_bytes(a, elem);
+#ifdef MO_TUNING
   static const int env_threads = [] { const char* e = getenv("MO_GENERIC_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob
+#else
+  constexpr int env_threads = 0;
+#endif
   int threads = (a.n + a.k <= 48) ? 64 : kMaxThreads;  // measured: cfg 2 (P = 36) 8.5 M vs 6.8 M steps/s, cfg 3 (P = 72) 0.75 M vs 1.9 M
   if (env_threads == 256) threads = 256;  // (the register-distributed factorisation wants an 8 x 8 or a 16 x 16 thread grid)
   const int max_per_cu = 32 / (threads / 64);

@@ -39,8 +39,12 @@ struct mo_plan {
   // scratch for mo_qp_solve with J-level input: G [max_batch][n*n], c [max_batch][n]
   void* G_scratch;
   void* c_scratch;
-  void* H_work;        // generic kernel beyond its LDS-resident range: H workspaces of the persistent grid's workgroups
-  size_t H_work_bytes;
+  // generic kernel beyond its LDS-resident range: one H workspace per workgroup of the persistent grid.  Sized and allocated ONCE, in
+  // mo_plan_create, for every launch shape the plan can produce (the full system and the k = m = 0 system of mo_linearize / mo_fill_qp);
+  // launches only read these three fields -- no allocation, no synchronisation, nothing plan-owned changes on the launch path.
+  void* H_work;
+  long long H_work_stride;  // elements per workgroup slot
+  long long H_work_slots;   // workgroup slots allocated: a launch's grid is clamped to it
   void* tile_scratch;  // fused Solve: per wave slot of the persistent grid, the G tiles a wave cannot park in LDS between passes
   unsigned long long* ticket;  // device work counter of the fused kernels (zeroed on the stream before each launch)
 };
@@ -98,16 +102,26 @@ int fill_problem(const mo_plan* plan, const mo_problem* prob, int64_t batch, boo
 // shape predicates.
 enum KernelChoice { KERNEL_FUSED_F64, KERNEL_FUSED_F32, KERNEL_GENERIC };
 
+// The product library reads NO environment variable (the reference has none): kernel selection and scheduling follow the
+// plan flags of include/mini_opt_hip.h only.  The getenv knobs of the A/B scripts exist in builds with -DMO_TUNING (tools/ab_build.sh).
 bool generic_forced(const mo_plan* plan) {
+#ifdef MO_TUNING
   static const bool env_force_generic = getenv("MO_FORCE_GENERIC") != nullptr;  // A/B and bisection knob
-  return env_force_generic || (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
+  if (env_force_generic) return true;
+#endif
+  return (plan->desc.flags & MO_PLAN_FORCE_GENERIC) != 0;
 }
 
 // Launches of at most this many problems per wave of the persistent grid are split statically (KernelArgs::static_rounds): -1 = the launcher's
-// own choice per kernel family (launch_fused / launch_fused_f32); A/B knob MO_FUSED_STATIC_ROUNDS (0 = tickets always)
-int fused_static_rounds() {
+// own choice per kernel family (launch_fused / launch_fused_f32); MO_PLAN_TICKETS_ALWAYS -> 0, MO_PLAN_STATIC_ROUNDS_ALWAYS -> every launch
+int fused_static_rounds(const mo_plan* plan) {
+#ifdef MO_TUNING
   static const int v = [] { const char* e = getenv("MO_FUSED_STATIC_ROUNDS"); return e ? atoi(e) : -1; }();
-  return v;
+  if (v >= 0) return v;
+#endif
+  if (plan->desc.flags & MO_PLAN_TICKETS_ALWAYS) return 0;
+  if (plan->desc.flags & MO_PLAN_STATIC_ROUNDS_ALWAYS) return 1 << 30;
+  return -1;
 }
 
 KernelChoice choose_kernel(const mo_plan* plan, const mo::KernelArgs& a) {
@@ -121,7 +135,7 @@ KernelChoice choose_kernel(const mo_plan* plan, const mo::KernelArgs& a) {
 int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice choice, void* stream) {
   if (a_in.batch == 0) return MO_OK;
   mo::KernelArgs a = a_in;
-  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(plan); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   MO_HIP_CHECK(hipSetDevice(plan->desc.device));
   hipStream_t s = (hipStream_t)stream;
   if (choice == KERNEL_FUSED_F64) {
@@ -129,19 +143,13 @@ int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice 
   } else if (choice == KERNEL_FUSED_F32) {
     MO_HIP_CHECK(mo::launch_fused_f32(a, plan->num_cus, s));
   } else {
-    if (mo::generic_needs_large(a, plan->elem)) {  // H in a global workspace per workgroup (lazily allocated, plan-owned)
+    if (mo::generic_needs_large(a, plan->elem)) {  // H in a global workspace per workgroup: plan-owned, allocated by mo_plan_create
       const size_t need = mo::generic_large_lds_bytes(a, plan->elem);
       if (need > 160 * 1024)
         return fail(MO_ERR_UNSUPPORTED, "n = %d, k = %d, m = %d: not even the state / residual vectors of one problem fit the 160 KiB of LDS", a.n, a.k, a.m);
-      const size_t per_wg = mo::generic_large_workspace_elems(a);
-      const size_t bytes = (size_t)mo::generic_large_grid(a, plan->elem, plan->num_cus) * per_wg * plan->elem;
-      mo_plan* mp = const_cast<mo_plan*>(plan);
-      if (!mp->H_work || mp->H_work_bytes < bytes) {
-        if (mp->H_work) { MO_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(mp->H_work); mp->H_work = nullptr; }
-        if (hipMalloc(&mp->H_work, bytes) != hipSuccess) { mp->H_work = nullptr; (void)hipGetLastError(); return fail(MO_ERR_HIP, "hipMalloc of the %zu B workspace of H failed", bytes); }
-        mp->H_work_bytes = bytes;
-      }
-      a.H_work = mp->H_work; a.H_work_stride = (long long)per_wg;
+      if (!plan->H_work || (long long)mo::generic_large_workspace_elems(a) > plan->H_work_stride)
+        return fail(MO_ERR_UNSUPPORTED, "the plan owns no H workspace for n = %d, k = %d (created for n = %d, k = %d)", a.n, a.k, plan->desc.n, plan->desc.k);
+      a.H_work = plan->H_work; a.H_work_stride = plan->H_work_stride; a.H_work_slots = plan->H_work_slots;
     }
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
@@ -150,7 +158,7 @@ int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice 
 
 int launch(const mo_plan* plan, const mo::KernelArgs& a_in, void* stream) {
   mo::KernelArgs a = a_in;
-  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(plan); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   return launch_chosen(plan, a, choose_kernel(plan, a), stream);
 }
 
@@ -241,7 +249,8 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   p->c_scratch = nullptr;
   p->tile_scratch = nullptr;
   p->H_work = nullptr;
-  p->H_work_bytes = 0;
+  p->H_work_stride = 0;
+  p->H_work_slots = 0;
   p->ticket = nullptr;
   if (hipMalloc((void**)&p->ticket, 256) != hipSuccess) {
     delete p;
@@ -251,7 +260,31 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   memset(&a, 0, sizeof(a));
   a.n = desc->n; a.k = desc->k; a.m = desc->m; a.m_r = desc->m_r;
   p->generic_lds = mo::generic_lds_bytes(a, p->elem);
-  // fp64 systems up to n = 128 (k <= 31, m <= 256) run on the fused kernels even when the LDS-resident generic kernel cannot hold them
+  // fp64 systems up to n = 128 (k <= 63, m <= 256) run on the fused kernels even when the LDS-resident generic kernel cannot hold them.
+  // Beyond the LDS-resident range the generic kernel keeps H in a global workspace per workgroup of its persistent grid: everything that
+  // sizes it is known here (shape, dtype, CU count), so it is allocated now -- for the larger of the two systems a plan launches there, the
+  // full one and the k = m = 0 one of mo_linearize / mo_fill_qp (fewer LDS bytes per workgroup, hence possibly MORE workgroups per CU) --
+  // and never touched again.  max_batch > 0 bounds the number of slots (a launch's grid never exceeds its batch).
+  if (mo::generic_needs_large(a, p->elem)) {
+    mo::KernelArgs lin = a;
+    lin.k = 0; lin.m = 0;
+    long long slots = mo::generic_large_grid(a, p->elem, p->num_cus);
+    if (desc->m_r > 0 && mo::generic_needs_large(lin, p->elem)) {
+      const long long ls = mo::generic_large_grid(lin, p->elem, p->num_cus);
+      if (ls > slots) slots = ls;
+    }
+    if (desc->max_batch > 0 && slots > desc->max_batch) slots = desc->max_batch;
+    const size_t per_wg = mo::generic_large_workspace_elems(a);   // (n + k) x ld: covers the n x ld(n) of the k = 0 system
+    const size_t bytes = (size_t)slots * per_wg * p->elem;
+    if (hipMalloc(&p->H_work, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(p->ticket);
+      delete p;
+      return fail(MO_ERR_HIP, "hipMalloc of the %zu B workspace of H (n = %d, k = %d: %lld workgroup slots) failed", bytes, desc->n, desc->k, slots);
+    }
+    p->H_work_stride = (long long)per_wg;
+    p->H_work_slots = slots;
+  }
 
   *out = p;
   return MO_OK;
@@ -275,7 +308,7 @@ const char* mo_plan_step_kernel(const mo_plan* plan, const mo_problem* prob) {
   a.mode = mo::MODE_STEP;
   a.vars = a.delta = reinterpret_cast<void*>(16);  // layout query only: assume 16-byte aligned, densely packed state / output
   a.vars_stride = a.delta_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
-  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(plan); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   switch (choose_kernel(plan, a)) {
     case KERNEL_FUSED_F64: return mo::fused_name(a, plan->desc.dtype);
     case KERNEL_FUSED_F32: return mo::fused_f32_name(a);
@@ -290,7 +323,7 @@ const char* mo_plan_solve_kernel(const mo_plan* plan, const mo_problem* prob) {
   a.mode = mo::MODE_SOLVE;
   a.vars = reinterpret_cast<void*>(16);  // layout query only
   a.vars_stride = plan->desc.n + 2 * plan->desc.m + plan->desc.k;
-  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(plan); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   switch (choose_kernel(plan, a)) {
     case KERNEL_FUSED_F64: return mo::fused_name(a, plan->desc.dtype);
     case KERNEL_FUSED_F32: return mo::fused_f32_name(a);
@@ -474,7 +507,7 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
   a.termination = termination; a.num_iterations = num_iterations; a.iterations = iterations; a.lagrange = lagrange;
   a.status = status;
   a.skip = skip; a.skip_stride = skip_stride; a.skip_active = skip_active;
-  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
+  a.ticket = plan->ticket; a.static_rounds = fused_static_rounds(plan); a.no_tiny = (plan->desc.flags & MO_PLAN_NO_TINY) != 0;
   const KernelChoice choice = choose_kernel(plan, a);
   const bool use_fused = choice != KERNEL_GENERIC;
   if (a.J && !use_fused) {  // the generic loop re-reads G after every factorisation: keep the linearised G, c in plan scratch

@@ -64,6 +64,7 @@ struct KernelArgs {
   int no_tiny;     // MO_PLAN_NO_TINY: keep n + k <= 15 on the 32-variable tile grid (set by mo_api.hip from the plan flags)
   // generic kernel beyond its LDS-resident range: P x ldh workspace of H per workgroup of the persistent grid (plan-owned)
   void* H_work; long long H_work_stride;
+  long long H_work_slots;   // workgroup slots behind H_work: the launch clamps its grid to it
   // diagnostics only (tools/phase_timer.hip builds kkt_fused.hip with MO_FUSED_STAMPS); NULL in the product
   unsigned long long* debug;
 };

@@ -208,7 +208,7 @@ class NLSSolverOutputs:
 
 class _Plan:
     def __init__(self, n, k, m, m_r, dtype, device, batch):
-        desc = L.PlanDesc(n, k, m, m_r, _DT[dtype], device.index or 0, 0, 0, batch)
+        desc = L.PlanDesc(n, k, m, m_r, _DT[dtype], device.index or 0, L.EXTRA_PLAN_FLAGS, 0, batch)
         self.h = C.c_void_p()
         L.check(L.lib().mo_plan_create(C.byref(desc), C.byref(self.h)))
 

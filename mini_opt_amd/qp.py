@@ -209,7 +209,7 @@ class QPInteriorPointSolver:
         ref = problem._any()
         self.batch = int(batch if batch is not None else ref.shape[0])
         desc = L.PlanDesc(problem.n, problem.k, problem.m, problem.m_r, _DT[problem.dtype],
-                          ref.device.index or 0, (L.MO_PLAN_FORCE_GENERIC if self._force_generic else 0) | (L.MO_PLAN_NO_TINY if self._no_tiny else 0), 0, self.batch)
+                          ref.device.index or 0, (L.MO_PLAN_FORCE_GENERIC if self._force_generic else 0) | (L.MO_PLAN_NO_TINY if self._no_tiny else 0) | L.EXTRA_PLAN_FLAGS, 0, self.batch)
         plan = C.c_void_p()
         L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
         self._plan = plan
@@ -330,7 +330,7 @@ class QPNullSpaceSolver:
         lib = L.lib()
         ref = p._any()
         B = max(int(t.shape[0]) for t in (p.J, p.G, p.A_eq) if t is not None)
-        desc = L.PlanDesc(p.n, p.k, 0, p.m_r, _DT[p.dtype], ref.device.index or 0, 0, 0, B)
+        desc = L.PlanDesc(p.n, p.k, 0, p.m_r, _DT[p.dtype], ref.device.index or 0, L.EXTRA_PLAN_FLAGS, 0, B)
         plan = C.c_void_p()
         L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
         try:
@@ -353,7 +353,7 @@ def linearize(problem: BatchedQP, force_generic: bool = False):
     ref = problem.J
     B, n = int(ref.shape[0]), problem.n
     desc = L.PlanDesc(n, 0, 0, problem.m_r, _DT[problem.dtype], ref.device.index or 0,
-                      L.MO_PLAN_FORCE_GENERIC if force_generic else 0, 0, B)
+                      (L.MO_PLAN_FORCE_GENERIC if force_generic else 0) | L.EXTRA_PLAN_FLAGS, 0, B)
     plan = C.c_void_p()
     L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
     try:

@@ -1429,13 +1429,17 @@ def test_fused_four_constraint_slots(n, k, m, m_r, level):
         assert agree >= B - 1, (strategy, tm, nit)
 
 
-def test_newton_step_is_graph_capturable():
+@pytest.mark.parametrize("shape", [None, (200, 10, 16, 24)], ids=["cfg2-fused", "n200-generic-large"])
+def test_newton_step_is_graph_capturable(shape):
     """mo_newton_step enqueues only a 8-byte memset and one kernel on the caller's stream: it can be captured into a HIP graph
-    (torch.cuda.graph) and replayed on new data in the same buffers."""
-    d = synth.CONFIGS["cfg2"]
-    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 64, stream=31)
+    (torch.cuda.graph) and replayed on new data in the same buffers.  Also beyond the LDS-resident range (n + k > 192): the generic kernel's
+    H workspaces belong to the plan and are allocated by mo_plan_create, the launch allocates and synchronises nothing."""
+    d = synth.CONFIGS["cfg2"] if shape is None else dict(n=shape[0], k=shape[1], m=shape[2], m_r=shape[3])
+    B = 64 if shape is None else 6
+    hb = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], B, stream=31)
     prob = batch_to_device(hb)
     s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel() == ("generic" if shape else "fused_mfma_f64_n32")
     s.SetVariables(T(hb.vars))
     mu = T(hb.mu)
     side = torch.cuda.Stream()
@@ -1446,7 +1450,7 @@ def test_newton_step_is_graph_capturable():
     with torch.cuda.graph(graph):
         delta, alpha, status = s.NewtonStep(mu, 0.995)
     # new state in the captured buffers, then replay
-    hb2 = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], 64, stream=32)
+    hb2 = synth.make_batch(d["n"], d["k"], d["m"], d["m_r"], B, stream=32)
     s.variables().copy_(T(hb2.vars)); mu.copy_(T(hb2.mu))
     prob.J.copy_(T(hb2.J)); prob.r.copy_(T(hb2.r)); prob.A_eq.copy_(T(hb2.A_eq)); prob.b_eq.copy_(T(hb2.b_eq))
     prob.cons_var.copy_(T(hb2.cons_var, torch.int32)); prob.cons_a.copy_(T(hb2.cons_a)); prob.cons_b.copy_(T(hb2.cons_b))
@@ -1456,6 +1460,60 @@ def test_newton_step_is_graph_capturable():
                                                             cons_var=hb2.cons_var, cons_a=hb2.cons_a, cons_b=hb2.cons_b, vars_=hb2.vars, mu=hb2.mu)
     assert torch.all(status == 0)
     assert rel_inf_rows(delta.cpu().numpy(), ref).max() < TOL64
+
+
+def test_large_generic_workspace_belongs_to_the_plan():
+    """Beyond the LDS-resident range the generic kernel keeps H in a global workspace per workgroup.  It is sized and allocated once, in
+    mo_plan_create, for every system the plan launches there -- the full one and the k = m = 0 one of mo_linearize / mo_fill_qp -- so
+    interleaving mo_newton_step, mo_linearize and mo_fill_qp on ONE plan neither allocates (device memory stays flat over repeated calls;
+    round 3 leaked 160-270 MB per linearisation through a stack copy of the plan) nor frees a workspace another call still owns (the step
+    is bit-identical before and after)."""
+    import ctypes as C
+    n, k, m, m_r, B = 200, 10, 16, 24, 6
+    hb = synth.make_batch(n, k, m, m_r, B, stream=91)
+    prob = batch_to_device(hb)
+    lib = L.lib()
+    desc = L.PlanDesc(n, k, m, m_r, L.MO_F64, 0, 0, 0, B)
+    plan = C.c_void_p()
+    L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
+    try:
+        ps = prob.as_struct()
+        assert lib.mo_plan_step_kernel(plan, C.byref(ps)).decode() == "generic"
+        V = n + 2 * m + k
+        vars_, mu = T(hb.vars), T(hb.mu)
+        delta = torch.empty(B, V, dtype=torch.float64, device=dev()); alpha = torch.empty(B, 2, dtype=torch.float64, device=dev())
+        status = torch.empty(B, dtype=torch.int32, device=dev())
+        G = torch.empty(B, n, n, dtype=torch.float64, device=dev()); c = torch.empty(B, n, dtype=torch.float64, device=dev())
+        f = torch.empty(B, dtype=torch.float64, device=dev()); cb = torch.empty(B, m, dtype=torch.float64, device=dev())
+        err = torch.empty(B, 2, dtype=torch.float64, device=dev()); st2 = torch.empty(B, dtype=torch.int32, device=dev())
+
+        def step():
+            L.check(lib.mo_newton_step(plan, C.byref(ps), B, Q._ptr(vars_), V, Q._ptr(mu), 1, 0.995, 0, Q._ptr(delta), V, Q._ptr(alpha),
+                                       Q._ptr(status), Q._stream()))
+
+        def linearise():
+            L.check(lib.mo_linearize(plan, C.byref(ps), B, Q._ptr(G), n * n, n, Q._ptr(c), n, Q._ptr(f), Q._stream()))
+
+        def fill():
+            L.check(lib.mo_fill_qp(plan, C.byref(ps), B, Q._ptr(vars_), V, Q._ptr(G), n * n, n, Q._ptr(c), n, Q._ptr(cb), m, Q._ptr(err),
+                                   Q._ptr(st2), Q._stream()))
+
+        step(); linearise(); fill()
+        torch.cuda.synchronize()
+        first = delta.clone()
+        ref, _, _, _ = orc.batched_newton_step(n, k, m, J=hb.J, r=hb.r, lam=hb.lam, A_eq=hb.A_eq, b_eq=hb.b_eq, cons_var=hb.cons_var,
+                                               cons_a=hb.cons_a, cons_b=hb.cons_b, vars_=hb.vars, mu=hb.mu)
+        assert torch.all(status == 0) and rel_inf_rows(first.cpu().numpy(), ref).max() < TOL64
+        Gd = np.einsum("bri,brj->bij", hb.J, hb.J) + hb.lam * np.eye(n)
+        assert np.abs(np.tril(G.cpu().numpy().transpose(0, 2, 1)) - np.tril(Gd)).max() < 1e-11   # column-major out: G[b] is G^T
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(4):
+            linearise(); step(); fill(); linearise()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20), (free0, torch.cuda.mem_get_info()[0])
+        assert torch.equal(delta, first)
+    finally:
+        lib.mo_plan_destroy(plan)
 
 
 @pytest.mark.parametrize("batch", [1, 2, 13])

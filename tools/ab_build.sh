@@ -13,7 +13,7 @@ for f in mo_api kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_n
   for g in "$@"; do [ "$g" = "$f.hip" ] && rebuilt=1; done
   if [ $rebuilt = 1 ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast \
-      -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-function-calls=false $flags -I"$src" -c "$src/$f.hip" -o "$tmp/$f.o" &
+      -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-function-calls=false -DMO_TUNING $flags -I"$src" -c "$src/$f.hip" -o "$tmp/$f.o" &
     objs="$objs $tmp/$f.o"
   else
     objs="$objs $src/$f.o"
