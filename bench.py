@@ -4,6 +4,12 @@
 A "step" = one pass of the hot path (mo_newton_step through the C ABI) over one batch of synthetic QPs that is already
 resident in HBM.
 
+`--mode solve` times the caller-facing entry point instead (SURVEY.md row f1; what ConstrainedNonlinearLeastSquares::ComputeStepDirection
+invokes, nonlinear.cc:221-247): a "step" is then ONE mo_qp_solve launch -- the whole interior-point Solve (qp.cc:100-151) of every QP of the
+batch from the NAIVE initial guess, iteration records included -- the unit is solves/s, `roofline` is algorithmic flops of the iterations
+the batch actually ran against the fp64 peak, `parity` compares termination state, iteration count and optimum of the problems with the
+oracle's Solve, and `cpu_baseline` is the oracle's Solve on the host cores.  `--strategy pc` selects PREDICTOR_CORRECTOR.
+
 Workloads (`--config`; the default follows `--gpus`):
   N = 1  -> cfg3 = BASELINE.json configs[2]: batch 65536, n=64 / 8 eq / 32 box, fp64, J-level input.
   N > 1  -> cfg5 = BASELINE.json configs[4]: 2^20 QPs of the cfg3 shape IN TOTAL, sharded contiguously over the N ranks with
@@ -16,6 +22,10 @@ Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: algorithmic byt
 measured with events on the launch stream, vs the 8 TB/s HBM peak) and `cpu_baseline` (the oracle's plain-C restatement
 of the reference step incl. the reference's explicit inverse, timed on the host cores on a bounded sample; rank 0, N=1;
 with the 1-core and the direct-solve variants SURVEY.md 8(d) asks for).
+
+At ANY N the line carries a correctness figure: after the timed region every rank checks a sample of ITS OWN shard against the oracle (the
+whole shard at N = 1, a 256-problem strided sample per rank at N > 1; `--parity-sample`), and MAX of the errors / SUM of the status words
+and disagreements travel over the control-plane group: `parity`, `status_ok` / `status_total` are all-rank figures.
 
 `--dry` rehearses the rank plumbing without a GPU (tests/test_bench_ranks_cpu.py: gloo, world size 2): the launch is replaced
 by a no-op and no device is touched; the JSON line then carries "dry": true and no measurement.
@@ -46,7 +56,7 @@ def kernel_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel_name: str, config: str, batch: int):
+def measured_traffic(kernel_name: str, config: str, batch: int, mode: str = "step"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected with tools/profile_pmc.sh):
     FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports half of wide 16 B/lane streaming reads, MI355X_MICROARCH.md HBM section)
     + WRITE_SIZE [KB] x 1024.  The counters cannot be read from inside this process, so the figure comes from the committed
@@ -55,8 +65,9 @@ def measured_traffic(kernel_name: str, config: str, batch: int):
     src = {"source": None}
     if not kernel_name.startswith("fused"):
         return None, src
-    want = {"cfg3": "r03_step_cfg3_pmc_summary.json", "cfg5": "r03_step_cfg5shard_pmc_summary.json",
-            "cfg2": "r03_step_cfg2_pmc_summary.json"}.get(config)
+    want = {("step", "cfg3"): "r04_step_cfg3_pmc_summary.json", ("step", "cfg5"): "r04_step_cfg5shard_pmc_summary.json",
+            ("step", "cfg2"): "r04_step_cfg2_pmc_summary.json", ("solve", "cfg3"): "r04_solve_cfg3_pmc_summary.json",
+            ("solve_pc", "cfg3"): "r04_solve_pc_cfg3_pmc_summary.json", ("solve", "cfg2"): "r04_solve_cfg2_pmc_summary.json"}.get((mode, config))
     if want is None:
         return None, src
     path = os.path.join(ROOT, "profiles", want)
@@ -167,10 +178,15 @@ def main():
     ap.add_argument("--config", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="default: cfg3 at --gpus 1, cfg5 (2^20 QPs in total, sharded) at --gpus > 1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--mode", default="step", choices=["step", "solve"],
+                    help="step: one mo_newton_step launch per step (the BASELINE metric); solve: one mo_qp_solve launch per step (solves/s)")
+    ap.add_argument("--strategy", default="complementarity", choices=["complementarity", "pc"], help="--mode solve: barrier strategy")
+    ap.add_argument("--no-records", action="store_true", help="--mode solve: without the per-iteration records")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--parity-sample", type=int, default=0, help="problems of the timed launch checked against the CPU restatement (0 = the whole batch)")
+    ap.add_argument("--parity-sample", type=int, default=0,
+                    help="problems of each rank's shard checked against the oracle, strided over the shard (0 = the whole shard at N = 1, 256 per rank at N > 1)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the K timed steps: back-to-back launches for at least this long, reported as `sustained` (0 = skip)")
     ap.add_argument("--dry", action="store_true", help="rank plumbing only: no GPU, the launch is a no-op (CPU tests)")
@@ -192,6 +208,13 @@ def main():
     config, cfg, batch, total_batch, scaling, workload = plan_workload(args, info)
     n, k, m, m_r = cfg["n"], cfg["k"], cfg["m"], cfg["m_r"]
     T = 8 if cfg["dtype"] == "f64" else 4
+    solve_mode = args.mode == "solve"
+    # mini_opt's ComputeStepDirection parameters (nonlinear.cc:226-231: initial_mu 1, sigma 0.1) with the iteration cap of qp.hpp:149
+    solve_kw = dict(initial_mu=1.0, sigma=0.1, max_iterations=10, termination_kkt_tol=1e-8 if T == 8 else 1e-3,
+                    barrier_strategy=2 if args.strategy == "pc" else 0)
+    if solve_mode:
+        workload = workload.replace("one mo_newton_step launch per step", "one mo_qp_solve launch per step (whole interior-point Solve from the NAIVE guess, "
+                                    + ("PREDICTOR_CORRECTOR" if args.strategy == "pc" else "COMPLEMENTARITY") + ", kkt tol %g, <= 10 iterations)" % solve_kw["termination_kkt_tol"])
 
     if args.dry:
         # RCCL is replaced by gloo and the launch by a no-op; everything else (sharding, barriers, MAX / SUM, the JSON line) is the
@@ -202,11 +225,14 @@ def main():
         kernel_name = "dry"
 
         def step():
-            return None, None, None
+            return None
         sync = lambda: None
     else:
+        import ctypes as C
+
         import torch
 
+        from mini_opt_amd import _lib as L
         from mini_opt_amd import qp as Q
         from mini_opt_amd import synth
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -223,11 +249,32 @@ def main():
         dtype = torch.float64 if cfg["dtype"] == "f64" else torch.float32
         prob, vars_, mu = synth.make_batch_torch(n, k, m, m_r, batch, dev, dtype, seed=synth.SEED + 1000 * info.rank)
         solver = Q.QPInteriorPointSolver(prob, force_generic=args.force_generic)
-        solver.SetVariables(vars_)
-        kernel_name = solver.step_kernel()
+        solver.SetVariables(vars_.clone())
+        if solve_mode:
+            # The launch itself, on preallocated outputs (the Python mirror's Solve allocates its result tensors per call): every call starts
+            # from the NAIVE guess (qp.cc:439-482 resets x, s, y, z), so repeated launches do identical work.
+            kernel_name = solver.solve_kernel()
+            sp = Q.Params(**solve_kw).as_struct()
+            V = n + 2 * m + k
+            term = torch.zeros(batch, dtype=torch.int32, device=dev)
+            nit = torch.zeros(batch, dtype=torch.int32, device=dev)
+            its = None if args.no_records else torch.zeros(batch, solve_kw["max_iterations"], L.MO_ITER_RECORD, dtype=dtype, device=dev)
+            lag = torch.zeros(batch, 2, dtype=dtype, device=dev)
+            svars = solver.variables()
+            status = torch.zeros(batch, dtype=torch.int32, device=dev)
+            lib, plan, pstruct = L.lib(), solver._plan, solver._prob
 
-        def step():
-            return solver.NewtonStep(mu, 0.995)
+            def step():
+                L.check(lib.mo_qp_solve(plan, C.byref(pstruct), batch, C.byref(sp), Q._ptr(svars), V, Q._ptr(term), Q._ptr(nit), Q._ptr(its),
+                                        Q._ptr(lag), Q._ptr(status), Q._stream()))
+                return None
+        else:
+            kernel_name = solver.step_kernel()
+            res = {}
+
+            def step():
+                res["out"] = solver.NewtonStep(mu, 0.995)
+                return None
         sync = torch.cuda.synchronize
 
     def barrier():
@@ -248,11 +295,10 @@ def main():
     if args.dry:
         for _ in range(args.steps):
             step()
-        delta = alpha = status = None
     else:
         for e0, e1 in evs:  # events sit on torch's current stream == the stream handed to the C ABI
             e0.record()
-            delta, alpha, status = step()
+            step()
             e1.record()
     sync()
     barrier()
@@ -260,12 +306,17 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed_max, total_units = sharding.barrier_max_sum(info, elapsed, batch * args.steps, tdev, tgroup)
 
+    unit = "solves/s" if solve_mode else "steps/s"
     out = None
     if info.rank == 0:
+        if solve_mode:
+            metric = f"batched interior-point QP solves/sec (mo_qp_solve, {args.strategy}), n={n} {cfg['dtype']}"
+        else:
+            metric = "batched dense KKT Newton steps/sec, n=64 fp64" if config in ("cfg3", "cfg5") else f"batched dense KKT Newton steps/sec ({config})"
         out = {
-            "metric": "batched dense KKT Newton steps/sec, n=64 fp64" if config in ("cfg3", "cfg5") else f"batched dense KKT Newton steps/sec ({config})",
+            "metric": metric,
             "value": total_units / elapsed_max,
-            "unit": "steps/s",
+            "unit": unit,
             "n_gpus": info.world_size,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -275,10 +326,71 @@ def main():
             "vs_baseline": None,
             "dtype": cfg["dtype"],
             "data": "synthetic",
-            "config": {"workload": workload, "name": config, "kernel": kernel_name, "batch_per_gpu": batch, "batch_total": total_batch,
+            "config": {"workload": workload, "name": config, "mode": args.mode, "kernel": kernel_name, "batch_per_gpu": batch, "batch_total": total_batch,
                        "n": n, "k": k, "m": m, "m_r": m_r, "parallelism": f"batch-sharded x{info.world_size}, no collectives"},
             "timing_sync": tlabel,   # what carried the barrier + MAX / SUM between the ranks ("none" at N = 1)
         }
+
+    # ---- correctness figure of the timed launch, on every rank (the checker leg: the only place besides cpu_baseline where bench.py touches
+    # oracle/).  Sample: the whole shard at N = 1, a strided sample per rank at N > 1; reduced over the control-plane (gloo) group.
+    import numpy as np
+    ns = args.parity_sample if args.parity_sample > 0 else (batch if info.world_size == 1 else min(batch, 256))
+    ns = max(1, min(ns, batch))
+    idx = np.unique(np.linspace(0, batch - 1, ns).astype(np.int64))
+    tol = 1e-10 if T == 8 else 2e-3
+    local = {"max_err": 0.0, "p999": 0.0, "disagree": 0, "ok": batch, "checked": int(len(idx)), "error": None, "extra": {}}
+    if not args.dry and not args.no_cpu_baseline:
+        try:
+            from oracle import oracle as orc
+            tix = torch.as_tensor(idx, device=dev)
+            h = lambda t: t.index_select(0, tix).double().cpu().numpy()
+            pr = dict(J=h(prob.J), r=h(prob.r), lam=float(np.float32(prob.lam)) if T == 4 else prob.lam, A_eq=h(prob.A_eq), b_eq=h(prob.b_eq),
+                      cons_var=prob.cons_var.index_select(0, tix).cpu().numpy(), cons_a=h(prob.cons_a), cons_b=h(prob.cons_b))
+            if solve_mode:
+                rterm, rnit, rvars, _ = orc.batched_solve(n, k, m, **pr, **solve_kw)
+                gterm, gnit, gvars = term.index_select(0, tix).cpu().numpy(), nit.index_select(0, tix).cpu().numpy(), h(svars)
+                xerr = np.max(np.abs(gvars[:, :n] - rvars[:, :n]), axis=1) / np.maximum(1.0, np.max(np.abs(rvars[:, :n]), axis=1))
+                same = (gterm == rterm) & (gnit == rnit)
+                # fp64: termination state and iteration count of every checked problem as the oracle's; the optimum within 1e-6 (the reference's own
+                # bound on its Solve KATs, qp_test.cc:252-471).  fp32 (no reference counterpart): iteration count within 2, optimum within 2e-2.
+                if T == 4:
+                    same = (gterm == rterm) & (np.abs(gnit - rnit) <= 2)
+                xtol = 1e-6 if T == 8 else 2e-2
+                local.update(max_err=float(xerr.max()), p999=float(np.quantile(xerr, 0.999)), disagree=int((~same).sum() + (xerr[same] >= xtol).sum()))
+                local["extra"] = {"oracle_mean_iterations": float(rnit.mean()), "oracle_satisfied_frac": float((rterm == 0).mean())}
+                tol = xtol
+            else:
+                delta, alpha, st_t = res["out"]
+                ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, **pr, vars_=h(vars_), mu=h(mu))
+                got = delta.index_select(0, tix).double().cpu().numpy()
+                err = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
+                st_s = st_t.index_select(0, tix).cpu().numpy()
+                local.update(max_err=float(err.max()), p999=float(np.quantile(err, 0.999)), disagree=int((ref_status != st_s).sum()))
+        except Exception as exc:  # the oracle is only the checker; never let it hide the measurement
+            local["error"] = repr(exc)[:300]
+    if not args.dry:
+        st_all = status if solve_mode else res["out"][2]
+        local["ok"] = int((st_all == 0).sum().item())
+    red = sharding.reduce_scalars(info, maxima=[local["max_err"], local["p999"], 1.0 if local["error"] else 0.0],
+                                  sums=[local["disagree"], local["ok"], batch, local["checked"]])
+    parity = None
+    if not args.no_cpu_baseline or args.dry:
+        parity = {"sample": int(red["sums"][3]), "sample_per_rank": int(len(idx)), "ranks": info.world_size, "max_rel_inf": red["maxima"][0],
+                  "p999_rel_inf": red["maxima"][1], "tolerance": tol,
+                  ("solve_disagreements" if solve_mode else "status_disagreements"): int(red["sums"][0]),
+                  "passed": bool(red["maxima"][0] < tol and red["sums"][0] == 0 and red["maxima"][2] == 0.0), **local["extra"]}
+        if solve_mode:
+            parity["what"] = ("termination state and iteration count equal to the oracle's Solve on every checked problem, x within "
+                              f"{tol:g} rel-inf (max_rel_inf is the x error)")
+        if red["maxima"][2] != 0.0:
+            parity["error"] = local["error"] or "the checker failed on another rank"
+        if args.dry:
+            parity["dry"] = True
+            parity["passed"] = None   # nothing was launched, nothing was checked: only the reduction ran
+    if info.rank == 0:
+        out["parity"] = parity
+        out["status_ok"], out["status_total"] = int(red["sums"][1]), int(red["sums"][2])
+
     if args.dry:
         if info.rank == 0:
             out["dry"] = True
@@ -290,8 +402,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    import numpy as np
-    from mini_opt_amd import synth
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
     # The K timed steps above are the contract's figure; K x ~1.4 ms is a short region, so the same launch is also run back to back
     # for >= --sustain-seconds (clock ramp, thermal state and the ticket counter's behaviour over thousands of launches included).
@@ -307,58 +417,68 @@ def main():
             dt = time.perf_counter() - ts
             if dt >= args.sustain_seconds:
                 break
-        sustained = {"value": batch * launches / dt, "unit": "steps/s", "seconds": dt, "launches": launches,
+        sustained = {"value": batch * launches / dt, "unit": unit, "seconds": dt, "launches": launches,
                      "ms_per_step": 1e3 * dt / launches, "scope": "rank 0" if info.world_size > 1 else "the GPU"}
-    ok = int((status == 0).sum().item())
     if info.rank == 0:
         alg_bytes = synth.algorithmic_bytes(n, k, m, m_r, T)
-        achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(kernel_name, config, batch)
         flops = synth.algorithmic_flops(n, k, m, m_r)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
-                           "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes * batch,
-                           "datapath": traffic_src.pop("datapath", None),
-                           "kernel_ms": kernel_ms, "scope": "rank 0's launches" if info.world_size > 1 else "the launch",
-                           "fp64_tflops": flops * batch / (kernel_ms * 1e-3) / 1e12,
-                           "fp64_frac_of_peak": flops * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-        out["status_ok"], out["status_total"] = ok, batch
         out["sustained"] = sustained
-        if cfg["dtype"] == "f32":  # cfg 4 is bound by the fp32 matrix cores (AI 37.5 flop/B vs ridge 19.7), not by HBM
-            tf = flops * batch / (kernel_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "algorithmic_flops_per_step": flops, "kernel_ms": kernel_ms,
-                               "hbm_gbs_algorithmic": achieved}
+        if solve_mode:
+            # Algorithmic flops of the work the batch actually did (SURVEY.md 8(d) terms): J^T J + J^T r once per problem; per iteration the
+            # KKT residual, the LDL^T and one solve (two for the predictor-corrector); one more residual for the final termination test.
+            P = n + k
+            f_lin = m_r * n * (n + 1) + 2 * m_r * n
+            f_res = 2 * n * n + 4 * k * n + 6 * m
+            f_fac = P ** 3 / 3.0
+            f_sol = 2 * P * P + 8 * m
+            its_total = float(nit.double().sum().item())
+            total_flops = batch * (f_lin + f_res) + its_total * (f_res + f_fac + f_sol * (2 if args.strategy == "pc" else 1))
+            tf = total_flops / (kernel_ms * 1e-3) / 1e12
+            peak = FP64_PEAK_TFLOPS if T == 8 else FP32_MFMA_PEAK_TFLOPS
+            traffic, traffic_src = measured_traffic(kernel_name, config, batch, mode="solve_pc" if args.strategy == "pc" else "solve")
+            # algorithmic HBM bytes of a Solve: the problem read once (J, r, A_eq, b_eq, constraints), the state / records / outputs written once
+            rec_bytes = 0 if args.no_records else T * 14 * solve_kw["max_iterations"]
+            alg_solve = T * (m_r * n + m_r + k * n + k) + m * (4 + 2 * T) + T * (n + 2 * m + k) + rec_bytes + 2 * T + 12
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": traffic,
+                               "traffic_provenance": traffic_src, "algorithmic_flops_per_launch": total_flops,
+                               "algorithmic_flops_per_solve_mean": total_flops / batch, "mean_iterations": its_total / batch,
+                               "satisfied_kkt_tol_frac": float((term == 0).double().mean().item()),
+                               "algorithmic_bytes_per_solve": alg_solve, "algorithmic_bytes_per_launch": alg_solve * batch,
+                               "hbm_gbs_algorithmic": alg_solve * batch / (kernel_ms * 1e-3) / 1e9,
+                               "kernel_ms": kernel_ms, "scope": "rank 0's launches" if info.world_size > 1 else "the launch"}
+        else:
+            achieved = alg_bytes * batch / (kernel_ms * 1e-3) / 1e9
+            traffic, traffic_src = measured_traffic(kernel_name, config, batch)
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
+                               "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes * batch,
+                               "datapath": traffic_src.pop("datapath", None),
+                               "kernel_ms": kernel_ms, "scope": "rank 0's launches" if info.world_size > 1 else "the launch",
+                               "fp64_tflops": flops * batch / (kernel_ms * 1e-3) / 1e12,
+                               "fp64_frac_of_peak": flops * batch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+            if cfg["dtype"] == "f32":  # cfg 4 is bound by the fp32 matrix cores (AI 37.5 flop/B vs ridge 19.7), not by HBM
+                tf = flops * batch / (kernel_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "algorithmic_flops_per_step": flops, "kernel_ms": kernel_ms,
+                                   "hbm_gbs_algorithmic": achieved}
 
-        # The cpu_baseline leg (rank 0 at N = 1 only; --no-cpu-baseline skips it entirely, e.g. under rocprofv3): the ONLY place where
-        # bench.py touches oracle/ -- once as the checker of a sample of the launch just timed, once as the timed CPU baseline.
-        out["parity"] = None
+        # The cpu_baseline leg (rank 0 at N = 1 only; --no-cpu-baseline skips it entirely, e.g. under rocprofv3): the oracle timed on the host cores
         try:
             if info.world_size > 1 or args.no_cpu_baseline:
                 raise StopIteration
             from oracle import oracle as orc
-            ns = batch if args.parity_sample <= 0 else min(args.parity_sample, batch)  # max and 99.9th percentile over the whole batch
-            sl = slice(0, ns)
-            h = lambda t: t[sl].double().cpu().numpy()
-            ref, ref_alpha, ref_status, _ = orc.batched_newton_step(
-                n, k, m, J=h(prob.J), r=h(prob.r), lam=float(np.float32(prob.lam)) if T == 4 else prob.lam,
-                A_eq=h(prob.A_eq), b_eq=h(prob.b_eq), cons_var=prob.cons_var[sl].cpu().numpy(), cons_a=h(prob.cons_a),
-                cons_b=h(prob.cons_b), vars_=h(vars_), mu=h(mu))
-            got = delta[sl].double().cpu().numpy()
-            err = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
-            out["parity"] = {"sample": ns, "max_rel_inf": float(err.max()), "p999_rel_inf": float(np.quantile(err, 0.999)),
-                             "status_agree": bool(np.array_equal(ref_status, status[sl].cpu().numpy())),
-                             "tolerance": 1e-10 if T == 8 else 2e-3, "passed": bool(err.max() < (1e-10 if T == 8 else 2e-3))}
             cores = usable_cores()
             hs = lambda t, cnt: t[:cnt].double().cpu().numpy()
 
             def run_cpu(cnt, threads, use_inverse):
                 a = dict(J=hs(prob.J, cnt), r=hs(prob.r, cnt), lam=prob.lam, A_eq=hs(prob.A_eq, cnt), b_eq=hs(prob.b_eq, cnt),
-                         cons_var=prob.cons_var[:cnt].cpu().numpy(), cons_a=hs(prob.cons_a, cnt), cons_b=hs(prob.cons_b, cnt),
-                         vars_=hs(vars_, cnt), mu=hs(mu, cnt), use_inverse=use_inverse, num_threads=threads)
+                         cons_var=prob.cons_var[:cnt].cpu().numpy(), cons_a=hs(prob.cons_a, cnt), cons_b=hs(prob.cons_b, cnt), num_threads=threads)
                 t = time.perf_counter()
-                _, _, _, used = orc.batched_newton_step(n, k, m, **a)
+                if solve_mode:
+                    used = orc.batched_solve(n, k, m, **a, **solve_kw)[3]
+                else:
+                    used = orc.batched_newton_step(n, k, m, **a, vars_=hs(vars_, cnt), mu=hs(mu, cnt), use_inverse=use_inverse)[3]
                 return time.perf_counter() - t, used
 
             def timed_variant(threads, use_inverse, seconds):
@@ -371,22 +491,30 @@ def main():
                     t, used = run_cpu(cnt, threads, use_inverse)
                     reps.append(t)
                     t_total += t
-                return {"value": cnt / float(np.median(reps)), "unit": "steps/s", "cores": used,
+                return {"value": cnt / float(np.median(reps)), "unit": unit, "cores": used,
                         "sample": f"first {cnt} problems of the same batch, {len(reps)} repeats (median)"}
 
-            # all cores and one core, with the reference's explicit inverse (qp.cc:310-311) and with a direct solve
-            main_v = timed_variant(cores, True, args.cpu_seconds * 0.5)
-            out["cpu_baseline"] = {
-                **main_v, "kind": "port",
-                "sample": main_v["sample"] + ", OpenMP over problems; plain-C restatement of the reference step incl. its explicit "
-                          "inverse (qp.cc:310-311); Eigen itself is absent from the image",
-                "one_core": timed_variant(1, True, args.cpu_seconds * 0.15),
-                "direct": timed_variant(cores, False, args.cpu_seconds * 0.2),
-                "direct_one_core": timed_variant(1, False, args.cpu_seconds * 0.15)}
+            if solve_mode:
+                main_v = timed_variant(cores, True, args.cpu_seconds * 0.7)
+                out["cpu_baseline"] = {
+                    **main_v, "kind": "port",
+                    "sample": main_v["sample"] + ", OpenMP over problems; plain-C restatement of QPInteriorPointSolver::Solve (qp.cc:100-151) incl. the "
+                              "reference's explicit inverse per iteration; Eigen itself is absent from the image",
+                    "one_core": timed_variant(1, True, args.cpu_seconds * 0.3)}
+            else:
+                # all cores and one core, with the reference's explicit inverse (qp.cc:310-311) and with a direct solve
+                main_v = timed_variant(cores, True, args.cpu_seconds * 0.5)
+                out["cpu_baseline"] = {
+                    **main_v, "kind": "port",
+                    "sample": main_v["sample"] + ", OpenMP over problems; plain-C restatement of the reference step incl. its explicit "
+                              "inverse (qp.cc:310-311); Eigen itself is absent from the image",
+                    "one_core": timed_variant(1, True, args.cpu_seconds * 0.15),
+                    "direct": timed_variant(cores, False, args.cpu_seconds * 0.2),
+                    "direct_one_core": timed_variant(1, False, args.cpu_seconds * 0.15)}
         except StopIteration:
             pass
         except Exception as exc:  # the oracle is only the checker; never let it hide the measurement
-            out["parity"] = {"error": repr(exc)}
+            out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if info.world_size > 1:
         dist.barrier()

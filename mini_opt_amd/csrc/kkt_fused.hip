@@ -978,6 +978,7 @@ __device__ inline void solve_second_rhs(const d4 (&U)[(NT + NY) * (NT + NY)], in
 #pragma unroll
         for (int t = 0; t < 4; ++t) q2 = fma(U[pa * NB + pb][t], wr[t], q2);
         rb[pb] += cross_row_sum(q2);
+        if constexpr (NY >= 2) asm volatile("" : "+v"(rb[pb]));   // one cross-row sum at a time (register pressure: 168 tile registers)
       }
       lds_fence();                        // hop has been read before the next block overwrites it
     }
@@ -1578,7 +1579,7 @@ template <int NT, int WPS, int MC = 1, int NY = 1> struct SolveCfg {
 
 __device__ inline double wave_sum_f64(double v) { return cross_row_sum(row_sum(v)); }
 
-template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR, int NY = 1>
+template <int NT, int WPS, int SW, bool QPL, int MC = 1, int JMODE = JMODE_VECTOR, int NY = 1, bool PCK = true>
 __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const KernelArgs a) {
   using C = SolveCfg<NT, WPS, MC, NY>;
   constexpr int N = C::N, NB = NT + NY, LT = NB - 1, SLOT = C::SLOT, D = C::D;  // LT: the tile column that carries the right-hand side
@@ -1846,7 +1847,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     double mu_used = mu;   // the mu handed to the previous Iterate
     // Mehrotra predictor-corrector (qp.cc:170-187): solve with mu = 0, probe alpha(tau = 1), then solve again with the second-order
     // term ds_aff dz_aff and mu = sigma mu_input on the right-hand side -- through the factors of the first solve (solve_second_rhs).
-    const bool use_pc = (iterate_mode ? ka->barrier_strategy : ka->sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
+    // (PCK = false: an instantiation without the corrector's code -- its second solve keeps every factor tile alive behind the back-substitution,
+    // which with two y tiles on the 64 grid is what does not fit 256 registers; the launcher picks by barrier strategy)
+    const bool use_pc = PCK && (iterate_mode ? ka->barrier_strategy : ka->sp.barrier_strategy) == MO_PREDICTOR_CORRECTOR && m > 0;
 
     while (st == MO_STATUS_OK) {
       const bool include_ineq = !guess_pass && !(residual_mode && (ka->flags & MO_STEP_NO_INEQUALITIES));
@@ -1873,9 +1876,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         diagS[2 * lane] = 0.0; diagS[2 * lane + 1] = 0.0;
         rhoS[2 * lane] = 0.0; rhoS[2 * lane + 1] = 0.0;
       }
-      double cvec[NT];
+      // c (= J^T r, or the caller's c) goes to LDS (cpark: behind the parked tiles, inside the drained ring) as soon as it exists and is read
+      // back where the residual needs it: nothing of it occupies registers during the tile products
       if (QPL && build_now) {
+        double cvec[NT];
         load_g_tiles<NT, NY>((const double*)ka->G + p * ka->G_stride, ka->G_ld, (const double*)ka->c + p * ka->c_stride, nn, g, j, U, cvec);
+        if (g == 0) {
+#pragma unroll
+          for (int c = 0; c < NT; ++c) cpark[16 * c + j] = cvec[c];
+        }
       } else if (stream_now) {
         double cpart[NT];
 #pragma unroll
@@ -1887,7 +1896,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? lam : 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) cvec[c] = cross_row_sum(cpart[c]);
+        for (int c = 0; c < NT; ++c) {
+          const double cv = cross_row_sum(cpart[c]);
+          if (g == 0) cpark[16 * c + j] = cv;
+        }
       } else {  // fetch what the first pass parked
         int ti = 0;
 #pragma unroll
@@ -1898,8 +1910,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
             else U[ta * NB + tb] = *(const d4*)(Gt + ((size_t)(ti - PARK_LDS) * 64 + lane) * 4);
           }
         }
-#pragma unroll
-        for (int c = 0; c < NT; ++c) cvec[c] = cpark[16 * c + j];
       }
       if (build_now && can_park && !iterate_mode) {  // park the tiles and c for the following passes (the stream has drained: the ring is free)
         int ti = 0;
@@ -1910,10 +1920,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
             if (ti < PARK_LDS) *(d4*)(park + (ti * 64 + lane) * 4) = U[ta * NB + tb];
             else *(d4*)(Gt + ((size_t)(ti - PARK_LDS) * 64 + lane) * 4) = U[ta * NB + tb];
           }
-        }
-        if (g == 0) {
-#pragma unroll
-          for (int c = 0; c < NT; ++c) cpark[16 * c + j] = cvec[c];
         }
         tiles_cached = true;
       }
@@ -1952,6 +1958,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       for (int b = 0; b < NB; ++b) acc1[b] = 0.0;
 #pragma unroll
       for (int ra = 0; ra < NB; ++ra) {
+        // compiler-level memory barrier: the row operands of tile row ra are fetched HERE -- hipcc otherwise hoists the LDS reads of all tile
+        // rows above the first one (32 registers live across the whole product at n = 64; its own pressure report: 293 with two y tiles)
+        asm volatile("" ::: "memory");
         double vR[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) vR[t] = ra < NT ? xp[16 * ra + g + 4 * t] : 0.0;
@@ -1971,14 +1980,27 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
             if (j == 0) tmp[16 * ra + g + 4 * t] = pt;
           }
         }
+        // One tile row at a time: the empty asm statements pin the partial sums of this row HERE.  hipcc otherwise sinks the whole chains of
+        // the y columns (acc1[NT ..]) to their use behind the loop and keeps the row operands of ALL tile rows alive until then -- 32 registers
+        // at n = 64 (its own pressure report for two y tiles: 293 live registers at that point).
+#pragma unroll
+        for (int b = ra; b < NB; ++b) asm volatile("" : "+v"(acc1[b]));
       }
       lds_fence();
-      {
-        double azv[NT];
-        ldv<NT, QPL>(azS, j, azv);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cvec[c] - azv[c];  // qp.cc:404-406, 415
+      for (int h = 0; h < NT / 2; ++h) {   // (per pair of tiles, as ldv reads azS; two y tiles: one pair at a time, see part B)
+        if constexpr (NY >= 2) asm volatile("" ::: "memory");
+        double azv[2];
+        if (QPL) { azv[0] = azS[32 * h + j]; azv[1] = azS[32 * h + 16 + j]; }
+        else { const d2 av = *(const d2*)(azS + 32 * h + 2 * j); azv[0] = av[0]; azv[1] = av[1]; }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = 2 * h + e;
+          r_d[c] = cross_row_sum(acc1[c]) + tmp[16 * c + j] + cpark[16 * c + j] - azv[e];  // qp.cc:404-406, 415
+          if constexpr (NY >= 2) asm volatile("" : "+v"(r_d[c]));   // computed HERE (hipcc sinks the sums behind the r_pe branches, operands alive)
+        }
       }
+      if constexpr (NY >= 2) asm volatile("" ::: "memory");
       {
         const double* const bp = (const double*)ka->b + p * ka->b_stride;
 #pragma unroll
@@ -2085,15 +2107,20 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         }
       }
       lds_fence();
-      {
-        double dd[NT], rr[NT];
-        ldv<NT, QPL>(diagS, j, dd);
-        ldv<NT, QPL>(rhoS, j, rr);
+      // (two y tiles: 168 tile registers -- the loops below fetch their LDS operands one tile at a time, behind compiler-level memory barriers,
+      // instead of all sixteen / thirty-two values up front)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) {
+      for (int h = 0; h < NT / 2; ++h) {   // tiles 2h, 2h + 1: ldv's pair layout (QPL: positions 16 (2h) + j, 16 (2h + 1) + j)
+        if constexpr (NY >= 2) asm volatile("" ::: "memory");
+        double dd[2], rr[2];
+        if (QPL) { dd[0] = diagS[32 * h + j]; dd[1] = diagS[32 * h + 16 + j]; rr[0] = rhoS[32 * h + j]; rr[1] = rhoS[32 * h + 16 + j]; }
+        else { const d2 dv = *(const d2*)(diagS + 32 * h + 2 * j), rv = *(const d2*)(rhoS + 32 * h + 2 * j); dd[0] = dv[0]; dd[1] = dv[1]; rr[0] = rv[0]; rr[1] = rv[1]; }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? dd[c] : 0.0;
-          if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[c]);          // -r_aug, position order (qp.cc:337-342)
+        for (int e = 0; e < 2; ++e) {
+          const int c = 2 * h + e;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) U[c * NB + c][t] += (j == g + 4 * t) ? dd[e] : 0.0;
+          if (g == 0) tmp[16 * c + j] = -(r_d[c] + rr[e]);          // -r_aug, position order (qp.cc:337-342)
           if (g == 0) azS[16 * c + j] = r_d[c];                     // r_d for the corrector's right-hand side (azS is dead: r_d consumed it)
         }
       }
@@ -2104,12 +2131,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       lds_fence();
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
+        if constexpr (NY >= 2) asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const double rv = tmp[16 * c + g + 4 * t];
           if (j == kRC) U[c * NB + LT][t] = rv;
         }
       }
+      if constexpr (NY >= 2) asm volatile("" ::: "memory");
 #pragma unroll
       for (int t = 0; t < 4; ++t) {  // last y diagonal tile = [0, -r_pe; -r_pe^T, 0]
         double v = 0.0;
@@ -2520,8 +2549,11 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
     if (qgrid > qneed) qgrid = qneed;
     if (qgrid < 1) qgrid = 1;
     const dim3 qgd((unsigned)qgrid), qbd(256 * wq);
+    // (J-level on the 64 grid: the instantiation with the corrector's code needs 20 B of scratch, the one without none -- picked by strategy)
+    const bool pc = (a.mode == MODE_SOLVE ? a.sp.barrier_strategy : a.barrier_strategy) == MO_PREDICTOR_CORRECTOR && a.mode != MODE_RESIDUAL;
     if (a.n > 32) {
-      if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false, 2>), qgd, qbd, 0, stream, a);
+      if (a.J && !pc) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false, 2, JMODE_VECTOR, 1, false>), qgd, qbd, 0, stream, a);
+      else if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, false, 2>), qgd, qbd, 0, stream, a);
       else hipLaunchKernelGGL((kkt_fused_solve_kernel<4, 2, 3, true, 2>), qgd, qbd, 0, stream, a);
     } else {
       if (a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<2, 3, 3, false, 2>), qgd, qbd, 0, stream, a);

@@ -33,16 +33,26 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
     else if (gather) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, 1, JMODE_GATHER, 2>), gd, bd, 0, stream, a);            \
     else hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, MC_, JMODE_VECTOR, 2>), gd, bd, 0, stream, a);                      \
   } while (0)
+  // The corrector's second solve keeps all 21 factor tiles of the 64 grid alive behind the back-substitution: with it the kernel needs more
+  // than the 256 registers of two waves per SIMD (84 B of scratch per lane), without it none.  Hence two instantiations on the 32 / 64 grids,
+  // picked by barrier strategy: PCK = false for COMPLEMENTARITY / FIXED_DECREASE (and the KKT residual), PCK = true for PREDICTOR_CORRECTOR.
+  const bool pc = (a.mode == MODE_SOLVE ? a.sp.barrier_strategy : a.barrier_strategy) == MO_PREDICTOR_CORRECTOR && a.mode != MODE_RESIDUAL;
+#define MO_NY2S(NT_, WPS_, MC_, PCK_)                                                                                                    \
+  do {                                                                                                                                   \
+    if (!a.J) hipLaunchKernelGGL((kkt_fused_solve_kernel<NT_, WPS_, 3, true, MC_, JMODE_VECTOR, 2, PCK_>), gd, bd, 0, stream, a);        \
+    else if (gather) hipLaunchKernelGGL((kkt_fused_solve_kernel<NT_, WPS_, 3, false, 1, JMODE_GATHER, 2, PCK_>), gd, bd, 0, stream, a);  \
+    else hipLaunchKernelGGL((kkt_fused_solve_kernel<NT_, WPS_, 3, false, MC_, JMODE_VECTOR, 2, PCK_>), gd, bd, 0, stream, a);            \
+  } while (0)
   if (solve) {  // two constraint slots per lane on the 32 / 64 grids only (fused_supported)
     switch (grid_tile) {
-      case 2: MO_NY2(kkt_fused_solve_kernel, 2, 3, 2); break;
+      case 2: if (pc) MO_NY2S(2, 3, 2, true); else MO_NY2S(2, 3, 2, false); break;
       case 4:
 #ifdef MO_TUNING
         if (solve64_one_wave) { if (one_slot) MO_NY2(kkt_fused_solve_kernel, 4, 1, 1); else MO_NY2(kkt_fused_solve_kernel, 4, 1, 2); }
         else
 #endif
-        if (one_slot) MO_NY2(kkt_fused_solve_kernel, 4, 2, 1);
-        else MO_NY2(kkt_fused_solve_kernel, 4, 2, 2);
+        if (one_slot) { if (pc) MO_NY2S(4, 2, 1, true); else MO_NY2S(4, 2, 1, false); }
+        else { if (pc) MO_NY2S(4, 2, 2, true); else MO_NY2S(4, 2, 2, false); }
         break;
       case 6: MO_NY2(kkt_fused_solve_kernel, 6, 1, 1); break;
       default: MO_NY2(kkt_fused_solve_kernel, 8, 1, 1); break;
@@ -55,6 +65,7 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
       default: MO_NY2(kkt_fused_f64_kernel, 8, 1, 2); break;
     }
   }
+#undef MO_NY2S
 #undef MO_NY2
   return hipGetLastError();
 }

@@ -83,3 +83,17 @@ def barrier_max_sum(info: RankInfo, elapsed_s: float, units: int, device=None, g
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), int(u.item())
+
+
+def reduce_scalars(info: RankInfo, maxima=(), sums=()) -> dict:
+    """MAX of `maxima` and SUM of `sums` over all ranks, over the DEFAULT (control-plane, gloo) group: the correctness figures of a
+    multi-rank bench line (parity errors, status words) never depend on RCCL.  Returns {"maxima": [...], "sums": [...]}."""
+    if info.world_size == 1:
+        return {"maxima": [float(v) for v in maxima], "sums": [int(v) for v in sums]}
+    import torch
+    import torch.distributed as dist
+    mx = torch.tensor([float(v) for v in maxima] or [0.0], dtype=torch.float64)
+    sm = torch.tensor([int(v) for v in sums] or [0], dtype=torch.int64)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    return {"maxima": [float(v) for v in mx.tolist()][:len(maxima)], "sums": [int(v) for v in sm.tolist()][:len(sums)]}

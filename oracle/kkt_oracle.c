@@ -821,3 +821,62 @@ int orc_batched_newton_step(int batch, int n, int k, int m, int m_r, const doubl
   }
   return used;
 }
+
+int orc_batched_solve(int batch, int n, int k, int m, int m_r, const double* J, int row_major, const double* r,
+                      double lambda, const double* G, const double* c, const double* A_eq, const double* b_eq,
+                      const int* cons_var, const double* cons_a, const double* cons_b, const orc_params* params,
+                      int num_threads, double* vars_io, int* termination, int* num_iterations) {
+  const int V = n + 2 * m + k;
+  int used = 1;
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+  used = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  (void)num_threads;
+#endif
+#pragma omp parallel
+  {
+    double* Gl = (double*)malloc(sizeof(double) * (size_t)n * n);
+    double* cl = (double*)malloc(sizeof(double) * (size_t)n);
+    orc_iteration* its = (orc_iteration*)malloc(sizeof(orc_iteration) * (size_t)(params->max_iterations > 0 ? params->max_iterations : 1));
+    orc_solver s;
+    int have_solver = 0;
+#pragma omp for schedule(dynamic, 16)
+    for (int p = 0; p < batch; ++p) {
+      orc_qp qp;
+      qp.n = n; qp.k = k; qp.m = m;
+      if (J) {
+        orc_linearize_dense(m_r, n, J + (size_t)p * m_r * n, row_major, r + (size_t)p * m_r, lambda, Gl, cl);
+        qp.G = Gl; qp.c = cl;
+      } else {
+        qp.G = G + (size_t)p * n * n; qp.c = c + (size_t)p * n;
+      }
+      qp.A_eq = A_eq ? A_eq + (size_t)p * k * n : NULL;
+      qp.b_eq = b_eq ? b_eq + (size_t)p * k : NULL;
+      qp.cons_var = cons_var ? cons_var + (size_t)p * m : NULL;
+      qp.cons_a = cons_a ? cons_a + (size_t)p * m : NULL;
+      qp.cons_b = cons_b ? cons_b + (size_t)p * m : NULL;
+      int bad = 0;
+      for (int i = 0; i < m; ++i) bad |= (qp.cons_var[i] < 0 || qp.cons_var[i] >= n);
+      num_iterations[p] = 0;
+      if (bad) { termination[p] = -3; continue; }
+      if (!have_solver) {
+        if (orc_solver_setup(&s, &qp) != 0) { termination[p] = -1; continue; }
+        have_solver = 1;
+      } else {
+        s.qp = qp;
+        memset(s.H, 0, sizeof(double) * (size_t)s.P * s.P);   /* Setup re-zeroes H_ (qp.cc:47) */
+      }
+      memcpy(s.variables, vars_io + (size_t)p * V, sizeof(double) * (size_t)V);
+      int nit = 0;
+      termination[p] = orc_solve(&s, params, its, &nit);
+      num_iterations[p] = nit;
+      memcpy(vars_io + (size_t)p * V, s.variables, sizeof(double) * (size_t)V);
+    }
+    if (have_solver) orc_solver_free(&s);
+    free(its);
+    free(Gl);
+    free(cl);
+  }
+  return used;
+}

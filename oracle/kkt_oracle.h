@@ -181,6 +181,15 @@ int orc_batched_newton_step(int batch, int n, int k, int m, int m_r, const doubl
                             const double* cons_b, const double* vars, const double* mu, double tau,
                             int use_inverse, int num_threads, double* delta, double* alpha, int* status);
 
+/* Batched, OpenMP-parallel Solve (qp.cc:100-151 per problem through orc_solve, one re-used solver per thread like qp_test.cc:531-539):
+ * the checker and CPU baseline of `bench.py --mode solve`.  Same slabs as orc_batched_newton_step; vars_io [batch][V] holds the caller's
+ * state on entry (read only with ORC_GUESS_USER_PROVIDED) and the final iterate on exit; termination [batch] = orc_solve's return value,
+ * num_iterations [batch].  Returns threads used. */
+int orc_batched_solve(int batch, int n, int k, int m, int m_r, const double* J, int row_major, const double* r,
+                      double lambda, const double* G, const double* c, const double* A_eq, const double* b_eq,
+                      const int* cons_var, const double* cons_a, const double* cons_b, const orc_params* params,
+                      int num_threads, double* vars_io, int* termination, int* num_iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,8 +12,12 @@ for every branch a Solve takes, how far the deciding quantity was from flipping:
                    (a tie moves a step length between 1 and tau)
   slack_floor      s = max(1e-9, a x + b) of the initial guess                 (qp.cc:470-481)   min_i |a x + b - 1e-9| / 1e-9
 
-A test that lets a device result differ from the oracle's must show `min_margin` of that problem below KNIFE_EDGE; a disagreement on a
-problem whose every decision was clear of its threshold is a bug.
+A test that lets a device result differ from the oracle's must show one decision of that problem closer to its threshold than the
+threshold of ITS KIND (`closeness(margins) < 1`); a disagreement on a problem whose every decision was clear of its threshold is a bug.
+
+Not logged: the tau = 1 probe of PREDICTOR_CORRECTOR (qp.cc:174).  At tau = 1 the step length min(1, -v / dv) is continuous across
+v + dv = 0, so a "tie" there is not a branch that can flip; and with mu = 0 the identity s dz + z ds = -s z drives (z + dz) / z = -ds / s
+to zero as the iteration converges, so such a margin would fall below any threshold on nearly every converged run and excuse everything.
 """
 import ctypes as C
 
@@ -21,10 +25,13 @@ import numpy as np
 
 from . import oracle as orc
 
-# Two implementations agree to ~1e-15 per operation, but the quantities compared here are differences of O(|K| |x|) terms that have
-# converged to ~tol: an absolute rounding error of 1e-15 |K||x| (~1e-13 at the tests' scales) against tol = 1e-6..1e-9 is a relative
-# margin of up to ~1e-4 at the tightest tolerance; late iterations amplify state differences by |x| / |dx|.
-KNIFE_EDGE = 1.0e-4
+# One threshold per KIND of decision.  Termination and the mu gate compare residual norms that have converged to ~tol: an absolute rounding
+# error of 1e-15 |K||x| (~1e-13 at the tests' scales) against tol = 1e-6..1e-9 is a relative margin of up to ~1e-4 at the tightest tolerance.
+# A step-length tie compares v + dv with 0 relative to max(|v|, |dv|): two summation orders differ there by ~1e-12 even in late iterations
+# (every disagreement ever observed had a tie margin <= 5.7e-12, profiles/r03_fuzz_soak.txt), so 1e-9 is already generous; the slack floor
+# compares a x + b with 1e-9 in a quantity of O(1).
+KNIFE_EDGE = 1.0e-4   # termination / mu_gate
+THRESHOLDS = {"termination": KNIFE_EDGE, "mu_gate": KNIFE_EDGE, "alpha_tie_s": 1.0e-9, "alpha_tie_z": 1.0e-9, "slack_floor": 1.0e-9}
 
 
 def _kmax(e):
@@ -71,10 +78,6 @@ def solve_with_margins(qp, vars0=None, **kw):
             d = s.delta
             margins.append((it, "alpha_tie_s", _tie(before[N:N + M], d[N:N + M])))
             margins.append((it, "alpha_tie_z", _tie(before[N + M + K:], d[N + M + K:])))
-            if p.barrier_strategy == orc.PREDICTOR_CORRECTOR:
-                da = s.delta_affine
-                margins.append((it, "probe_tie_s", _tie(before[N:N + M], da[N:N + M])))
-                margins.append((it, "probe_tie_z", _tie(before[N + M + K:], da[N + M + K:])))
         s.evaluate_kkt(True)
         kmax = _kmax(s.compute_errors(mu))
         cur_mu = s.compute_mu()
@@ -98,16 +101,29 @@ def solve_with_margins(qp, vars0=None, **kw):
 
 
 def min_margin(margins):
-    """(smallest relative margin, its (iteration, name)) of one Solve."""
+    """(smallest relative margin, its (iteration, name)) of one Solve -- raw margins, for reports."""
     if not margins:
         return np.inf, None
     i = int(np.argmin([m[2] for m in margins]))
     return margins[i][2], margins[i][:2]
 
 
+def closeness(margins):
+    """(min over the decisions of margin / threshold of its kind, (iteration, name, raw margin)): below 1 the run sits on a knife edge."""
+    if not margins:
+        return np.inf, None
+    ratios = [m[2] / THRESHOLDS[m[1]] for m in margins]
+    i = int(np.argmin(ratios))
+    return float(ratios[i]), (margins[i][0], margins[i][1], margins[i][2])
+
+
+def on_knife_edge(margins):
+    return closeness(margins)[0] < 1.0
+
+
 class Disagreements:
     """Collects the problems on which a device result differs from the oracle's and enforces the rule: each of them must sit on a knife
-    edge (min_margin < KNIFE_EDGE).  `report()` is what the test prints / asserts at the end."""
+    edge (closeness < 1: one decision nearer to its threshold than the threshold of its kind).  `report()` is what the test prints."""
 
     def __init__(self, label):
         self.label, self.total, self.items = label, 0, []
@@ -116,11 +132,11 @@ class Disagreements:
         self.total += 1
         if agrees:
             return
-        mm, where = min_margin(margins)
-        self.items.append((tag, mm, where))
-        assert mm < KNIFE_EDGE, (f"{self.label}: {tag} differs from the oracle although no decision of the oracle's run was closer than "
-                                 f"{mm:.3e} (relative) to its threshold ({where})")
+        ratio, where = closeness(margins)
+        self.items.append((tag, ratio, where))
+        assert ratio < 1.0, (f"{self.label}: {tag} differs from the oracle although no decision of the oracle's run was near its threshold "
+                             f"(closest: {where}, {ratio:.3g} x the knife-edge threshold of its kind)")
 
     def report(self):
-        return (f"{self.label}: {len(self.items)} of {self.total} differ from the oracle, all on a knife edge; margins "
-                + ", ".join(f"{mm:.1e}@{where}" for _, mm, where in self.items))
+        return (f"{self.label}: {len(self.items)} of {self.total} differ from the oracle, all on a knife edge; "
+                + ", ".join(f"{tag}: margin {where[2]:.1e} at iteration {where[0]} ({where[1]})" for tag, _, where in self.items))

@@ -236,7 +236,7 @@ class ConstrainedNonlinearLeastSquares:
         _, its = s.solve(**qp_kw)
         if self.track_margins:
             from . import margins as _margins
-            self._note("qp", _margins.min_margin(_margins.solve_with_margins(oq, **qp_kw)[3])[0])
+            self._note("qp", _margins.closeness(_margins.solve_with_margins(oq, **qp_kw)[3])[0])   # margin / threshold of its kind: < 1 = knife edge
         x, _, y, _ = s.blocks(s.variables)
         linf = float(np.max(np.abs(y))) if k > 0 else None  # qp.cc:539-546
         return x.copy(), linf, False, len(its)

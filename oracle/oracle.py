@@ -92,6 +92,9 @@ def lib():
                                               C.c_double, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp,
                                               C.c_double, C.c_int, C.c_int, _dp, _dp, _ip]
         L.orc_batched_newton_step.restype = C.c_int
+        L.orc_batched_solve.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp, _dp, _dp, _dp,
+                                        _ip, _dp, _dp, C.c_void_p, C.c_int, _dp, _ip, _ip]
+        L.orc_batched_solve.restype = C.c_int
         _lib = L
     return _lib
 
@@ -288,3 +291,29 @@ def batched_newton_step(n, k, m, *, J=None, r=None, lam=0.0, G=None, c=None, A_e
                                          _d(mu), tau, int(use_inverse), num_threads, _d(delta), _d(alpha),
                                          _i(status))
     return delta, alpha, status, used
+
+
+def batched_solve(n, k, m, *, J=None, r=None, lam=0.0, G=None, c=None, A_eq=None, b_eq=None, cons_var=None, cons_a=None,
+                  cons_b=None, vars0=None, batch=None, num_threads=0, row_major=True, **params):
+    """OpenMP batched Solve (qp.cc:100-151 per problem) on contiguous [batch][...] slabs: the checker and the CPU baseline of
+    `bench.py --mode solve`.  Returns (termination [B] (orc_solve's value: >= 0 termination state, < 0 -status), iterations [B],
+    final variables [B, V], threads used)."""
+    V = n + 2 * m + k
+    if batch is None:
+        batch = (J if J is not None else G).shape[0]
+    m_r = 0 if J is None else J.shape[1]
+    cc = lambda a, dt=np.float64: None if a is None else np.ascontiguousarray(a, dtype=dt)
+    J, r, G, c, A_eq, b_eq, cons_a, cons_b = map(cc, (J, r, G, c, A_eq, b_eq, cons_a, cons_b))
+    cons_var = cc(cons_var, np.int32)
+    p = _Params()
+    lib().orc_default_params(C.byref(p))
+    for key, val in params.items():
+        if not hasattr(p, key):
+            raise KeyError(key)
+        setattr(p, key, val)
+    vars_io = np.zeros((batch, V)) if vars0 is None else np.array(vars0, dtype=np.float64, order="C", copy=True)
+    term = np.zeros(batch, dtype=np.int32)
+    nit = np.zeros(batch, dtype=np.int32)
+    used = lib().orc_batched_solve(batch, n, k, m, m_r, _d(J), int(row_major), _d(r), lam, _d(G), _d(c), _d(A_eq), _d(b_eq),
+                                   _i(cons_var), _d(cons_a), _d(cons_b), C.byref(p), num_threads, _d(vars_io), _i(term), _i(nit))
+    return term, nit, vars_io, used

@@ -40,6 +40,21 @@ def test_two_ranks_default_to_config5_sharded():
     assert out["units_per_step_all_ranks"] == 2 ** 20      # SUM over ranks of the shard sizes: the whole of config 5
     assert (out["config"]["n"], out["config"]["k"], out["config"]["m"], out["config"]["m_r"]) == (64, 8, 32, 128)
     assert out["dtype"] == "f64" and out["unit"] == "steps/s" and out["higher_is_better"] is True
+    # the correctness figures of a multi-rank line: every rank contributes a sample of ITS shard, MAX / SUM over the control-plane group
+    # (here the reduction runs on placeholders: --dry launches and checks nothing, `passed` says so)
+    par = out["parity"]
+    assert par["ranks"] == 2 and par["sample_per_rank"] == 256 and par["sample"] == 512 and par["dry"] is True and par["passed"] is None
+    assert {"max_rel_inf", "p999_rel_inf", "tolerance", "status_disagreements"} <= set(par)
+    assert out["status_ok"] == out["status_total"] == 2 ** 20     # SUM over ranks of the per-rank status counts
+
+
+def test_two_ranks_solve_mode_schema():
+    """`--mode solve`: one mo_qp_solve launch per step, unit solves/s, same line contract and the same all-rank parity block."""
+    out = _run(2, ["--mode", "solve", "--config", "cfg3", "--batch", "4096", "--parity-sample", "64"])
+    assert out["unit"] == "solves/s" and out["config"]["mode"] == "solve" and "mo_qp_solve" in out["config"]["workload"]
+    assert out["config"]["batch_total"] == 8192 and out["units_per_step_all_ranks"] == 8192
+    assert out["parity"]["sample"] == 128 and "solve_disagreements" in out["parity"]
+    assert out["status_ok"] == out["status_total"] == 8192
 
 
 def test_two_ranks_weak_scaling_config():

@@ -25,12 +25,18 @@ def test_two_ranks_on_one_gpu_run_config5_shards():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--config", "cfg5", "--batch", "16384", "--no-cpu-baseline"]
+           "--config", "cfg5", "--batch", "16384"]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
+    # the N > 1 line carries its own correctness figure: both ranks checked a strided 256-problem sample of their shard against the oracle,
+    # reduced over the gloo control plane; no cpu_baseline at N > 1
+    par = out["parity"]
+    assert par["passed"] is True and par["ranks"] == 2 and par["sample"] == 512 and par["max_rel_inf"] < 1e-10 and par["status_disagreements"] == 0
+    assert out["status_ok"] == out["status_total"] == out["config"]["batch_total"] == 32768
+    assert "cpu_baseline" not in out
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "strong"
     assert out["config"]["name"] == "cfg5" and out["config"]["batch_per_gpu"] == 16384 and out["config"]["batch_total"] == 32768
     assert out["config"]["kernel"] == "fused_mfma_f64_n64"
@@ -74,3 +80,30 @@ def test_two_ranks_on_one_gpu_fall_back_from_rccl_to_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["batch_total"] == 16384 and out["status_ok"] == out["status_total"]
     assert out["timing_sync"] == "rccl" or out["timing_sync"].startswith("gloo (rccl unavailable"), out["timing_sync"]
+
+
+def test_solve_mode_two_ranks_and_single_rank():
+    """`bench.py --mode solve` (one mo_qp_solve launch per step): two ranks on the one GPU with the all-rank parity block -- termination state and
+    iteration count of every checked problem equal to the oracle's Solve, optimum within 1e-6 -- and the single-rank line with the flop roofline
+    and the oracle's Solve as cpu_baseline."""
+    env = dict(os.environ, MO_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "solve", "--steps", "3", "--warmup", "1", "--config", "cfg3",
+           "--batch", "8192", "--sustain-seconds", "0"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["unit"] == "solves/s" and out["n_gpus"] == 2 and out["config"]["kernel"] == "fused_solve_mfma_f64_n64"
+    assert out["parity"]["passed"] is True and out["parity"]["sample"] == 512 and out["parity"]["solve_disagreements"] == 0
+    assert out["status_ok"] == out["status_total"] == 16384
+    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["unit"] == "TFLOP/s" and 0 < out["roofline"]["frac"] < 1
+    assert 6.0 < out["roofline"]["mean_iterations"] < 10.0
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "solve", "--steps", "3", "--warmup", "1", "--batch", "4096", "--sustain-seconds", "0",
+           "--cpu-seconds", "2"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["parity"]["passed"] is True and out["parity"]["sample"] == 4096      # the whole batch at N = 1
+    assert out["cpu_baseline"]["unit"] == "solves/s" and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["one_core"]["cores"] == 1
+    assert out["value"] > 20 * out["cpu_baseline"]["value"]

@@ -110,13 +110,9 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
             ref_solve.append((term, len(its), o2.variables.copy(), M.solve_with_margins(qp, **kw)[3]))
         tag = (seed, trial, level, n, k, m, m_r, strategy, guess)
         for family, force in (("fused", False), ("generic", True)):
-            try:
-                s = Q.QPInteriorPointSolver(prob, force_generic=force)
-                s.SetVariables(T(vars_))
-                ip, st = s.Iterate(T(np.full(B, 0.05)), strategy)
-            except Exception as e:                      # the generic kernel cannot hold n + k > ~141 in LDS
-                assert force and "LDS" in str(e), (tag, e)
-                continue
+            s = Q.QPInteriorPointSolver(prob, force_generic=force)   # (the generic kernel takes every size: H in a global workspace beyond the LDS)
+            s.SetVariables(T(vars_))
+            ip, st = s.Iterate(T(np.full(B, 0.05)), strategy)
             if not force:
                 assert s.solve_kernel().startswith("fused"), (tag, s.solve_kernel())
             assert torch.all(st == 0), (tag, family)
@@ -139,7 +135,10 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
                     xs = max(1.0, np.abs(ref_solve[p][2][:n]).max())
                     assert np.abs(v[p][:n] - ref_solve[p][2][:n]).max() <= 1e-5 * xs, (tag, family, p)
             checked[family] += 1
-    assert checked["fused"] == 30 and checked["generic"] >= 15, checked
+    assert checked["fused"] == 30 and checked["generic"] == 30, checked
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     for family in ("fused", "generic"):
         print(dis[family].report())
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_soak.txt"), "a") as f:
+            f.write(dis[family].report() + "\n")    # the soak record (profiles/r04_fuzz_soak.txt): every disagreement with its margin
         assert len(dis[family].items) <= 0.05 * dis[family].total, dis[family].report()

@@ -77,7 +77,7 @@ def run_both(oprob, dprob, oparams, dparams, guesses):
 NLS_KNIFE_EDGE = 1.0e-8
 
 
-def knife_edge_rule(label, oprob, oparams, guesses, term, nit, rterm, rnit, retraction=None, max_fraction=0.1):
+def knife_edge_rule(label, oprob, oparams, guesses, term, nit, rterm, rnit, retraction=None, max_fraction=0.05):
     """The problems whose (termination, iteration count) differ from the oracle's must each sit on a knife edge of the ORACLE's run: the
     oracle is re-run with decision margins logged.  Returns the mask of agreeing problems; the findings go to
     gpurun_out/nls_disagreements.jsonl."""
@@ -94,9 +94,9 @@ def knife_edge_rule(label, oprob, oparams, guesses, term, nit, rterm, rnit, retr
         outer = min([(mm[2], mm[0], mm[1]) for mm in o.margins if mm[1] != "qp"], default=(np.inf, -1, ""))
         rows.append({"test": label, "problem": int(p), "device": [int(term[p]), int(nit[p])], "oracle": [int(rterm[p]), int(rnit[p])],
                      "min_qp_margin": float(qp), "min_outer_margin": float(outer[0]), "outer_decision": [int(outer[1]), outer[2]]})
-        assert qp < M.KNIFE_EDGE or outer[0] < NLS_KNIFE_EDGE, (
+        assert qp < 1.0 or outer[0] < NLS_KNIFE_EDGE, (    # ("qp" margins are margin / threshold of the decision's kind, oracle/margins.py)
             f"{label}: problem {p} ends {(term[p], nit[p])} on the device and {(rterm[p], rnit[p])} in the oracle although no decision of the "
-            f"oracle's run was near its threshold (inner QP {qp:.2e}, outer loop {outer[0]:.2e} at {outer[1:]})")
+            f"oracle's run was near its threshold (inner QP {qp:.2e} x its knife-edge threshold, outer loop {outer[0]:.2e} at {outer[1:]})")
     if rows:
         out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)

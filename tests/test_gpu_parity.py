@@ -55,26 +55,52 @@ def batch_to_device(hb, dt=torch.float64):
                        cons_b=T(hb.cons_b, dt))
 
 
-def solves_agree_or_knife_edge(tag, make_qp, kw, runs, max_fraction=0.12):
-    """`runs` = {label: (termination [B], iterations [B])} of device Solves of the same problems.  Wherever two runs differ, or one differs
-    from the oracle, the oracle is the referee (oracle/margins.py): the problem must sit on a knife edge of the ORACLE's run -- a decision
-    within rounding of its threshold -- or be one the oracle itself cannot converge on (MAX_ITERATIONS: random constraint sets can be
-    infeasible or degenerate, multipliers reach 1e12 and there is no trajectory to follow).  Returns the mask of problems on which every
-    run agrees with every other."""
+# Disagreements with the oracle are counted per TEST (a sweep calls solves_agree_or_knife_edge once per shape with a handful of problems):
+# every one of them needs its logged knife edge, a single call may hold at most one, and over a whole test they may not exceed 5 %.
+_TALLY = {"off": 0, "total": 0}
+
+
+@pytest.fixture(autouse=True)
+def _knife_edge_budget():
+    _TALLY["off"], _TALLY["total"] = 0, 0
+    yield
+    if _TALLY["total"] >= 20:
+        assert _TALLY["off"] <= 0.05 * _TALLY["total"], f"{_TALLY['off']} of {_TALLY['total']} Solves of this test differ from the oracle (each on a knife edge, but more than 5 %)"
+
+
+KNIFE_EDGE_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "qp_disagreements.jsonl")
+
+
+def solves_agree_or_knife_edge(tag, make_qp, kw, runs, max_fraction=0.05, max_count=1):
+    """`runs` = {label: (termination [B], iterations [B])} of device Solves of the same problems.  EVERY run is held to the oracle's Solve
+    (oracle/margins.py replays it with its decision margins): a run whose (termination, iteration count) differs from the oracle's is only
+    accepted on a problem where one decision of the ORACLE's run sat nearer to its threshold than the knife-edge threshold of its kind --
+    also when the oracle ends in MAX_ITERATIONS (no blanket exemption: the device must then end there too, or show the knife edge).
+    Every accepted disagreement is logged to gpurun_out/qp_disagreements.jsonl.  Returns the mask of problems on which all runs agree
+    with the oracle."""
     from oracle import margins as M
     labels = list(runs)
     B = len(runs[labels[0]][0])
     agree = np.ones(B, dtype=bool)
-    for a_ in labels[1:]:
-        agree &= (np.asarray(runs[a_][0]) == np.asarray(runs[labels[0]][0])) & (np.asarray(runs[a_][1]) == np.asarray(runs[labels[0]][1]))
-    for p in np.flatnonzero(~agree):
+    rows = []
+    for p in range(B):
         term, n_it, _, marg = M.solve_with_margins(make_qp(p), **kw)
-        if term == orc.MAX_ITERATIONS:
+        off = [l for l in labels if int(runs[l][0][p]) != term or int(runs[l][1][p]) != n_it]
+        if not off:
             continue
-        mm, where = M.min_margin(marg)
-        assert mm < M.KNIFE_EDGE, (f"{tag}: problem {p}: " + ", ".join(f"{l} ends ({int(runs[l][0][p])}, {int(runs[l][1][p])})" for l in labels)
-                                    + f", the oracle ({term}, {n_it}) with no decision closer than {mm:.2e} to its threshold ({where})")
-    assert (~agree).mean() <= max_fraction, (tag, float((~agree).mean()))
+        agree[p] = False
+        ratio, where = M.closeness(marg)
+        rows.append({"test": str(tag), "problem": int(p), "oracle": [int(term), int(n_it)], "runs": {l: [int(runs[l][0][p]), int(runs[l][1][p])] for l in labels},
+                     "closest_decision": list(where) if where else None, "margin_over_threshold": ratio})
+        assert ratio < 1.0, (f"{tag}: problem {p}: " + ", ".join(f"{l} ends ({int(runs[l][0][p])}, {int(runs[l][1][p])})" for l in labels)
+                             + f", the oracle ({term}, {n_it}) with no decision near its threshold (closest: {where}, {ratio:.3g} x the knife-edge threshold)")
+    if rows:
+        os.makedirs(os.path.dirname(KNIFE_EDGE_LOG), exist_ok=True)
+        with open(KNIFE_EDGE_LOG, "a") as f:
+            for row in rows:
+                f.write(json.dumps(row) + "\n")
+    _TALLY["off"] += int((~agree).sum()); _TALLY["total"] += B
+    assert (~agree).mean() <= max_fraction or (~agree).sum() <= max_count, (tag, float((~agree).mean()))
     return agree
 
 
@@ -763,6 +789,18 @@ def test_fused_f32_solve_iterate_residual(n, k, m, m_r, level):
         nit_g = g32["solve", strategy][1]
         off = np.minimum(np.abs(nit - nit64), np.abs(nit - nit_g))
         assert off[conv].max() <= 2, (nit, nit64, nit_g)
+        # ... and EXACTLY the fp64 oracle's count (and termination state) wherever every decision of the oracle's run on these fp32-rounded
+        # inputs was clear of its threshold by more than 1e-3 relative -- fp32 rounding (1e-7 relative, amplified by the conditioning of a
+        # late iterate) cannot flip such a decision
+        from oracle import margins as M
+        clear = 0
+        for p in np.flatnonzero(conv):
+            qp = orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+            oterm, onit, _, marg = M.solve_with_margins(qp, barrier_strategy=strategy, **kw)
+            if M.min_margin(marg)[0] > 1e-3:
+                clear += 1
+                assert (int(tm[p]), int(nit[p])) == (oterm, onit), (strategy, p, int(tm[p]), int(nit[p]), oterm, onit, M.min_margin(marg))
+        print(f"fp32 Solve n={n} strategy {strategy}: {clear} of {int(conv.sum())} converged problems have all oracle margins > 1e-3: iteration-exact")
         assert np.max(np.abs(xs_[conv][:, :n] - x64[conv][:, :n])) <= 5e-3 * max(1.0, np.abs(x64[:, :n]).max())
         # the records of the first iteration follow the fp64 ones
         _, _, _, rec64 = f64["solve", strategy]
@@ -1031,6 +1069,15 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
                           out.num_iterations.cpu().numpy(), out.termination_state.cpu().numpy(), extra)
         f, g_ = got[False], got[True]
         assert rel_inf_rows(f[0], g_[0]).max() < 1e-8, tag
+        # ... and both against the ORACLE's step (BASELINE tolerance: 1e-10 rel-inf): the kernels with three / four y tiles and the one-tile
+        # kernel's boundary shapes are pinned directly, not through the generic kernel
+        Gd = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); cd = np.einsum("bqi,bq->bi", J, r)
+        ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, G=np.tril(Gd).transpose(0, 2, 1).copy(), c=cd, A_eq=A if k else None, b_eq=b if k else None,
+                                                                cons_var=cv if m else None, cons_a=ca if m else None, cons_b=cb if m else None, vars_=vars_, mu=mu)
+        assert np.all(ref_status == 0), tag
+        assert rel_inf_rows(f[0], ref).max() < TOL64, (tag, rel_inf_rows(f[0], ref).max())
+        assert rel_inf_rows(g_[0], ref).max() < TOL64, (tag, rel_inf_rows(g_[0], ref).max())
+        np.testing.assert_allclose(f[1], ref_alpha, atol=1e-9, err_msg=str(tag))
         # the step without inequalities (dx, dy only; ds = dz = 0; alpha = 1) and the KKT residual with its four norms, fused vs generic
         (fd0, fa0, fr, fre), (gd0, ga0, gr, gre) = f[7], g_[7]
         np.testing.assert_allclose(fd0, gd0, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(gd0).max()), err_msg=str(tag))
@@ -1044,11 +1091,10 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
         np.testing.assert_allclose(f[1], g_[1], atol=1e-8, err_msg=str(tag))
         np.testing.assert_allclose(f[2], g_[2], rtol=1e-6, atol=1e-9, equal_nan=True, err_msg=str(tag))
         np.testing.assert_allclose(f[3], g_[3], rtol=1e-7, atol=1e-9, err_msg=str(tag))
-        Gd = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); cd = np.einsum("bqi,bq->bi", J, r)
         make_qp = lambda p: orc.QP(G=np.tril(Gd[p]), c=cd[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
         solve_kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=kkt_tol, max_iterations=10, barrier_strategy=strategy,
                         initial_guess_method=orc.GUESS_SOLVE_EQUALITY_CONSTRAINED if k else orc.GUESS_NAIVE)
-        same = solves_agree_or_knife_edge(tag, make_qp, solve_kw, {"fused": (f[6], f[5]), "generic": (g_[6], g_[5])}, max_fraction=0.25)
+        same = solves_agree_or_knife_edge(tag, make_qp, solve_kw, {"fused": (f[6], f[5]), "generic": (g_[6], g_[5])})   # (B = 9: at most one problem per shape, 5 % over the sweep)
         # optimum: x of the problems that converged (random constraint sets can be nearly degenerate: multipliers reach 1e12, the
         # interior-point loop runs into MAX_ITERATIONS and the two summation orders drift apart there)
         conv = same & (f[6] == Q.SATISFIED_KKT_TOL)
@@ -1061,8 +1107,7 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
             o32 = s32.Solve(Q.Params(initial_mu=1.0, sigma=0.1, termination_kkt_tol=kkt_tol, max_iterations=10, barrier_strategy=strategy,
                                      initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE))
             same32 = solves_agree_or_knife_edge(tag + ("32 grid",), make_qp, solve_kw,
-                                                {"one_tile": (f[6], f[5]), "grid32": (o32.termination_state.cpu().numpy(), o32.num_iterations.cpu().numpy())},
-                                                max_fraction=0.25)
+                                                {"one_tile": (f[6], f[5]), "grid32": (o32.termination_state.cpu().numpy(), o32.num_iterations.cpu().numpy())})
             c32 = same32 & (f[6] == Q.SATISFIED_KKT_TOL)
             if c32.any():
                 x32 = s32.variables().cpu().numpy()[c32][:, :n]
@@ -1108,15 +1153,13 @@ def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
     out = s.Solve(Q.Params(**kw))
     assert torch.all(out.status == 0)
     v = s.variables().cpu().numpy(); nit = out.num_iterations.cpu().numpy(); tm = out.termination_state.cpu().numpy()
-    agree = 0
-    for p in range(B):
-        o = orc.Solver(orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p]))
+    make_qp = lambda p: orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+    same = solves_agree_or_knife_edge((n, k, m, m_r, level), make_qp, kw, {"fused": (tm, nit)})   # (B = 7: at most one problem, and only on a logged knife edge)
+    for p in np.flatnonzero(same):
+        o = orc.Solver(make_qp(p))
         term, its = o.solve(**kw)
-        if tm[p] == term and nit[p] == len(its):
-            agree += 1
-            if term == Q.SATISFIED_KKT_TOL:
-                np.testing.assert_allclose(v[p][:n], o.variables[:n], rtol=1e-6, atol=1e-8)
-    assert agree >= B - 1
+        if term == Q.SATISFIED_KKT_TOL:
+            np.testing.assert_allclose(v[p][:n], o.variables[:n], rtol=1e-6, atol=1e-8)
 
 
 def test_large_fp64_plan_runs_on_both_kernel_families():
@@ -1410,9 +1453,11 @@ def test_fused_four_constraint_slots(n, k, m, m_r, level):
         out = s.Solve(Q.Params(barrier_strategy=strategy, **kw))
         assert torch.all(out.status == 0)
         v = s.variables().cpu().numpy(); nit = out.num_iterations.cpu().numpy(); tm = out.termination_state.cpu().numpy()
-        agree = 0
+        make_qp = lambda p: orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+        # the oracle as referee: a Solve that differs from the oracle's needs a logged knife edge (at most one of the six problems)
+        same = solves_agree_or_knife_edge((n, k, m, m_r, level, strategy), make_qp, dict(barrier_strategy=strategy, **kw), {"fused": (tm, nit)})
         for p in range(B):
-            qp = orc.QP(G=np.tril(G[p]), c=c[p], A_eq=A[p].T, b_eq=b[p], cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+            qp = make_qp(p)
             o = orc.Solver(qp)
             o.variables[:] = vars_[p]
             ost, oip = o.iterate(0.05, strategy)
@@ -1422,11 +1467,8 @@ def test_fused_four_constraint_slots(n, k, m, m_r, level):
             np.testing.assert_allclose(after[p], o.variables, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(o.variables).max()))
             o2 = orc.Solver(qp)
             term, its = o2.solve(barrier_strategy=strategy, **kw)
-            if tm[p] == term and nit[p] == len(its):
-                agree += 1
-                if term == Q.SATISFIED_KKT_TOL:
-                    np.testing.assert_allclose(v[p][:n], o2.variables[:n], rtol=1e-6, atol=1e-8)
-        assert agree >= B - 1, (strategy, tm, nit)
+            if same[p] and term == Q.SATISFIED_KKT_TOL:
+                np.testing.assert_allclose(v[p][:n], o2.variables[:n], rtol=1e-6, atol=1e-8)
 
 
 @pytest.mark.parametrize("shape", [None, (200, 10, 16, 24)], ids=["cfg2-fused", "n200-generic-large"])
@@ -1579,8 +1621,7 @@ def test_fused_odd_n_with_stacked_jacobian(n, k, m, m_r):
     np.testing.assert_allclose(res[False][0], res[True][0], rtol=1e-8, atol=1e-10)
     Gd = np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n); cd = np.einsum("bqi,bq->bi", J, r)
     make_qp = lambda p: orc.QP(G=np.tril(Gd[p]), c=cd[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
-    same = solves_agree_or_knife_edge((n, k, m, m_r), make_qp, kw, {"fused": (res[False][3], res[False][2]), "generic": (res[True][3], res[True][2])},
-                                      max_fraction=0.3)
+    same = solves_agree_or_knife_edge((n, k, m, m_r), make_qp, kw, {"fused": (res[False][3], res[False][2]), "generic": (res[True][3], res[True][2])})
     same &= res[False][3] == Q.SATISFIED_KKT_TOL
     np.testing.assert_allclose(res[False][1][same][:, :n], res[True][1][same][:, :n], rtol=1e-6, atol=1e-8)
 
