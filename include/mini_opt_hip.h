@@ -157,6 +157,12 @@ const char* mo_plan_solve_kernel(const mo_plan* plan, const mo_problem* prob);
 int mo_linearize(mo_plan* plan, const mo_problem* prob, int64_t batch, void* G_out, int64_t G_stride, int32_t G_ld,
                  void* c_out, int64_t c_stride, void* half_sq_out, void* stream);
 
+/* QP::ComputeEigenvalueStats (qp.hpp:122-123, qp.cc:12-16): out[p] = {min, max, min |.|} of the eigenvalues of the QP Hessian of problem p
+ * (QPEigenvalues, structs.hpp:267-275) -- of sym(G) from the lower triangle of (G, c) input, as Eigen's SelfAdjointEigenSolver reads it, or of
+ * G = J^T J + lambda I for (J, r, lambda) input (what LinearizeAndFillQP hands the reference's QP, nonlinear.cc:182-189).  Any n the plan
+ * accepts; computed in fp64 (Householder tridiagonalisation + Sturm-count multisection), written in the plan's dtype.  out: [batch][3]. */
+int mo_qp_eigenvalue_stats(mo_plan* plan, const mo_problem* prob, int64_t batch, void* out, void* stream);
+
 /* Replaces the whole of LinearizeAndFillQP (nonlinear.cc:170-214) for dense residual stacks.  The caller hands over the cost
  * stack (J, r, lambda[_vec]) and -- as prob->A_eq / prob->b_eq -- the equality residuals' Jacobian and values at the
  * linearisation point x (UpdateJacobian, residual.hpp:230-250, is a plain copy for a dense stack), plus the problem's
@@ -282,7 +288,8 @@ typedef struct {
   double max_lambda;
   double min_lambda;
   int32_t retraction;                  /* mo_retraction */
-  int32_t reserved;
+  int32_t log_qp_eigenvalues;          /* Params::log_qp_eigenvalues (nonlinear.hpp:122-123): non-zero = every outer iteration records the
+                                          QPEigenvalues of its QP Hessian into mo_nls_problem.qp_eigenvalues (nonlinear.cc:138) */
 } mo_nls_params;
 
 /* Device buffers of one batch (all owned by the caller; shapes per problem, strides in elements, plan dims n, k, m, m_r). */
@@ -305,6 +312,9 @@ typedef struct {
   void* qp_iterations;               /* NULL, or [max_iterations][batch][max_qp_iterations][MO_ITER_RECORD]: the QPInteriorPointIteration records
                                         of every outer iteration's QP (NLSIteration::qp_outputs, structs.hpp:288); the caller pre-fills NaN */
   void* qp_lagrange;                 /* NULL, or [max_iterations][batch][2]: QPLagrangeMultipliers {min, l_infinity} of each QP (k > 0) */
+  void* qp_eigenvalues;              /* required with params.log_qp_eigenvalues: [max_iterations][batch][3] = NLSIteration::qp_eigenvalues
+                                        {min, max, abs_min} of G = J^T J + lambda I of each outer iteration (structs.hpp:267-310); the caller
+                                        pre-fills NaN (iterations a problem never ran keep it) */
 } mo_nls_problem;
 
 typedef int (*mo_nls_eval_fn)(void* user, int32_t what, void* stream);  /* non-zero return aborts mo_nls_solve with MO_ERR_CALLBACK */

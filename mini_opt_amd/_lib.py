@@ -31,7 +31,7 @@ MO_KKT_RECORD, MO_IP_RECORD, MO_ITER_RECORD = 4, 6, 14
 EXPORTS = ["mo_version_string", "mo_status_string", "mo_last_error", "mo_default_solve_params", "mo_plan_create",
            "mo_plan_destroy", "mo_plan_step_kernel", "mo_plan_solve_kernel", "mo_plan_nls_uses_nullspace", "mo_linearize", "mo_kkt_residual", "mo_newton_step", "mo_iterate",
            "mo_qp_solve", "mo_fill_qp", "mo_nonlinear_errors", "mo_qp_cost_derivative",
-           "mo_default_nls_params", "mo_nls_solve", "mo_nullspace_solve", "mo_residual_eval"]
+           "mo_default_nls_params", "mo_nls_solve", "mo_nullspace_solve", "mo_residual_eval", "mo_qp_eigenvalue_stats"]
 
 
 class PlanDesc(C.Structure):
@@ -67,7 +67,7 @@ class NlsParams(C.Structure):
                 ("equality_penalty_initial", C.c_double), ("equality_penalty_scale_factor", C.c_double),
                 ("equality_penalty_rho", C.c_double), ("lambda_initial", C.c_double), ("lambda_failure_init", C.c_double),
                 ("lambda_decrease_on_success", C.c_double), ("lambda_decrease_on_restore", C.c_double),
-                ("max_lambda", C.c_double), ("min_lambda", C.c_double), ("retraction", C.c_int32), ("reserved", C.c_int32)]
+                ("max_lambda", C.c_double), ("min_lambda", C.c_double), ("retraction", C.c_int32), ("log_qp_eigenvalues", C.c_int32)]
 
 
 class NlsProblem(C.Structure):
@@ -79,7 +79,7 @@ class NlsProblem(C.Structure):
                 ("r_cand", C.c_void_p), ("r_cand_stride", C.c_int64), ("r_eq_cand", C.c_void_p), ("r_eq_cand_stride", C.c_int64),
                 ("cons_var", C.c_void_p), ("cons_a", C.c_void_p), ("cons_b", C.c_void_p), ("cons_stride", C.c_int64),
                 ("step", C.c_void_p), ("step_stride", C.c_int64), ("step_alpha", C.c_void_p), ("user_exit", C.c_void_p),
-                ("qp_iterations", C.c_void_p), ("qp_lagrange", C.c_void_p)]
+                ("qp_iterations", C.c_void_p), ("qp_lagrange", C.c_void_p), ("qp_eigenvalues", C.c_void_p)]
 
 
 NLS_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
     L.mo_qp_cost_derivative.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp, vp]
     L.mo_nullspace_solve.argtypes = [vp, C.POINTER(Problem), i64, vp, i64, vp, vp]
     L.mo_residual_eval.argtypes = [vp, i32, i32, vp, vp, i64, i64, vp, i64, vp, i64, i32, i32, vp]
+    L.mo_qp_eigenvalue_stats.argtypes = [vp, C.POINTER(Problem), i64, vp, vp]
     L.mo_default_nls_params.argtypes = [C.POINTER(NlsParams)]
     L.mo_default_nls_params.restype = None
     L.mo_nls_solve.argtypes = [vp, C.POINTER(NlsProblem), i64, C.POINTER(NlsParams), NLS_EVAL_FN, vp, vp, vp, vp, vp, vp]

@@ -61,6 +61,7 @@ struct KKTError {                                                               
 };
 struct QPInteriorPointIteration { KKTError kkt_initial{}; KKTError kkt_final{}; IPIterationOutputs ip_outputs{}; };  // :81-94
 struct QPLagrangeMultipliers { double min; double l_infinity; };                                     // structs.hpp:108-113
+struct QPEigenvalues { double min; double max; double abs_min; };                                    // structs.hpp:267-275
 struct QPInteriorPointSolverOutputs {                                                                // structs.hpp:116-134
   QPInteriorPointTerminationState termination_state{};
   std::vector<QPInteriorPointIteration> iterations;
@@ -99,6 +100,9 @@ struct QP {
   double& G_at(int i, int j) { return G[(size_t)i + (size_t)j * n]; }
   double& A_at(int q, int j) { return A_eq[(size_t)q + (size_t)j * k]; }
   void ResizeEqualities(int rows) { k = rows; A_eq.assign((size_t)rows * n, 0.0); b_eq.assign((size_t)rows, 0.0); }
+  // QP::ComputeEigenvalueStats (qp.hpp:122-123, qp.cc:12-16): the eigenvalue summary of G (its lower triangle, as SelfAdjointEigenSolver reads
+  // it), computed on the device through mo_qp_eigenvalue_stats.  Defined below (needs the device helpers).
+  inline QPEigenvalues ComputeEigenvalueStats(int device = 0) const;
 #ifdef MINI_OPT_HIP_HAS_EIGEN
   template <typename QPEigen> static QP FromEigen(const QPEigen& q) {  // any struct with the reference's members
     QP out((int)q.G.rows());
@@ -142,6 +146,22 @@ template <typename T> class DeviceBuffer {
   size_t count_{0};
 };
 }  // namespace detail
+
+inline QPEigenvalues QP::ComputeEigenvalueStats(int device) const {
+  mo_plan_desc d{}; d.n = n; d.k = 0; d.m = 0; d.m_r = 0; d.dtype = MO_F64; d.device = device; d.max_batch = 1;
+  mo_plan* plan = nullptr;
+  detail::check(mo_plan_create(&d, &plan));
+  struct Guard { mo_plan* p; ~Guard() { mo_plan_destroy(p); } } guard{plan};
+  detail::DeviceBuffer<double> Gd, cd, out(3);
+  Gd.Upload(G.data(), G.size()); cd.Upload(c.data(), c.size());
+  mo_problem pr{};
+  pr.G = Gd.get(); pr.G_stride = (int64_t)n * n; pr.G_ld = n; pr.c = cd.get(); pr.c_stride = n;
+  detail::check(mo_qp_eigenvalue_stats(plan, &pr, 1, out.get(), nullptr));
+  detail::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  double h[3];
+  out.Download(h, 3);
+  return QPEigenvalues{h[0], h[1], h[2]};
+}
 
 // A view of one block of the state vector (stands in for Eigen::VectorBlock, qp.cc:205-219).
 struct VectorBlock {
@@ -347,6 +367,7 @@ struct NLSIteration {
   double lambda{0.};
   Errors errors_initial{};
   int qp_termination_state{0}, qp_num_iterations{0}, qp_status{0};
+  std::optional<QPEigenvalues> qp_eigenvalues;   // when Params::log_qp_eigenvalues (structs.hpp:306-307, nonlinear.cc:138)
   DirectionalDerivatives directional_derivatives{};
   double penalty{0.};
   StepSizeSelectionResult step_result{StepSizeSelectionResult::SUCCESS};
@@ -380,6 +401,7 @@ class BatchedConstrainedNonlinearLeastSquares {
     double lambda_decrease_on_restore{0.8};
     double max_lambda{1.};
     double min_lambda{0.};
+    bool log_qp_eigenvalues{false};   // nonlinear.hpp:122-123
   };
   // x: [batch][n] evaluation points.  r: [batch][m_r], J: [batch][m_r][n] row-major (NULL when only errors are wanted),
   // r_eq: [batch][k], J_eq: [batch][k][n] row-major (both NULL when k == 0).
@@ -428,6 +450,7 @@ class BatchedConstrainedNonlinearLeastSquares {
     sp.lambda_decrease_on_success = p.lambda_decrease_on_success; sp.lambda_decrease_on_restore = p.lambda_decrease_on_restore;
     sp.max_lambda = p.max_lambda; sp.min_lambda = p.min_lambda;
     sp.retraction = retraction_ ? MO_RETRACT_CALLBACK : MO_RETRACT_EUCLIDEAN;
+    sp.log_qp_eigenvalues = p.log_qp_eigenvalues ? 1 : 0;
     mo_nls_problem np{};
     np.vars = vars_.get(); np.vars_stride = n_; np.candidate = cand_.get(); np.candidate_stride = n_;
     np.J = J_.get(); np.J_stride = (int64_t)m_r_ * n_; np.J_ld = n_; np.J_layout = MO_ROW_MAJOR; np.r = r_.get(); np.r_stride = m_r_;
@@ -447,6 +470,12 @@ class BatchedConstrainedNonlinearLeastSquares {
       std::vector<double> nanfill((size_t)batch_ * max_iterations_ * rec_, std::numeric_limits<double>::quiet_NaN());
       records_.Upload(nanfill.data(), nanfill.size());
     }
+    detail::DeviceBuffer<double> eig;
+    if (p.log_qp_eigenvalues) {   // [max_iterations][batch][3], NaN where a problem never ran the iteration
+      std::vector<double> nanfill((size_t)batch_ * max_iterations_ * 3, std::numeric_limits<double>::quiet_NaN());
+      eig.Upload(nanfill.data(), nanfill.size());
+      np.qp_eigenvalues = eig.get();
+    }
     iterations_done_ = 0;
     term_dev_ = term.get(); nit_dev_ = nit.get();
     callback_error_ = nullptr;
@@ -458,6 +487,8 @@ class BatchedConstrainedNonlinearLeastSquares {
     num_iterations_.resize((size_t)batch_); nit.Download(num_iterations_.data(), num_iterations_.size());
     std::vector<int32_t> t((size_t)batch_); term.Download(t.data(), t.size());
     std::vector<double> rec((size_t)batch_ * max_iterations_ * rec_); records_.Download(rec.data(), rec.size());
+    std::vector<double> eigh;
+    if (p.log_qp_eigenvalues) { eigh.resize((size_t)batch_ * max_iterations_ * 3); eig.Download(eigh.data(), eigh.size()); }
     outputs_.assign((size_t)batch_, NLSSolverOutputs{});
     std::vector<NLSTerminationState> out;
     for (int64_t b = 0; b < batch_; ++b) {
@@ -467,6 +498,10 @@ class BatchedConstrainedNonlinearLeastSquares {
         const double* r = rec.data() + ((size_t)b * max_iterations_ + it) * rec_;
         if (std::isnan(r[1])) break;  // QP_INDEFINITE ends a problem without logging the iteration (nonlinear.cc:103-105)
         outputs_[(size_t)b].iterations.push_back(Record(r, it));
+        if (p.log_qp_eigenvalues) {
+          const double* ev = eigh.data() + ((size_t)it * (size_t)batch_ + (size_t)b) * 3;
+          if (!std::isnan(ev[0])) outputs_[(size_t)b].iterations.back().qp_eigenvalues = QPEigenvalues{ev[0], ev[1], ev[2]};
+        }
       }
     }
     return out;

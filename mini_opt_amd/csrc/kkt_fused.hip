@@ -103,6 +103,35 @@ __device__ inline double row_sum(double v) {
 #endif
   return v;
 }
+// FOUR row sums at once (round 4).  p0 .. p3 are four values per lane whose sums over the 16 lanes of each row are wanted; the plain way is four
+// butterflies of four steps (48 VALU instructions: two 32-bit DPP moves and an add per step and value).  The transposed butterfly halves the number
+// of live values at each of the first two steps instead -- lanes exchange with j ^ 1 and keep p0 / p2 (even) or p1 / p3 (odd), then with j ^ 2 --
+// and finishes the one remaining value with two rotations inside the row: 27 VALU instructions, and lane j ends up with the sum of p[j & 3]
+// (all four quads of the row hold the same four sums).  A 64-bit DPP move only knows row_newbcast on this part, so the exchanges stay 32-bit pairs.
+// The first two steps add exactly what row_sum adds (a + b is commutative bit for bit); the last two pair the quad sums as (Q0 + Q3) + (Q2 + Q1)
+// where row_sum's mirrors give (Q0 + Q1) + (Q3 + Q2): same sum, last-bit differences are possible.
+__device__ inline int select_lanes32(unsigned long long mask, int if_set, int if_clear) {   // v_cndmask_b32 on a constant lane mask held in SGPRs
+  int r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+__device__ inline double select_lanes(unsigned long long mask, double if_set, double if_clear) {
+  return __hiloint2double(select_lanes32(mask, __double2hiint(if_set), __double2hiint(if_clear)),
+                          select_lanes32(mask, __double2loint(if_set), __double2loint(if_clear)));
+}
+// lanes exchange with j ^ 1 (XOR1) or j ^ 2: lanes of MASK keep `b` and send `a`, the others keep `a` and send `b`; every lane adds what it receives
+template <int CTRL, unsigned long long MASK> __device__ inline double exchange_add(double a, double b) {
+  const double keep = select_lanes(MASK, b, a), send = select_lanes(MASK, a, b);
+  return keep + dpp_f64<CTRL>(send);
+}
+__device__ inline double row_sum4_scatter(double p0, double p1, double p2, double p3) {   // lane j: sum over its row of p[j & 3]
+  const double q01 = exchange_add<0xB1, 0xAAAAAAAAAAAAAAAAull>(p0, p1);   // quad_perm [1,0,3,2]; odd lanes keep p1
+  const double q23 = exchange_add<0xB1, 0xAAAAAAAAAAAAAAAAull>(p2, p3);
+  double w = exchange_add<0x4E, 0xCCCCCCCCCCCCCCCCull>(q01, q23);         // quad_perm [2,3,0,1]; lanes with (j & 2) keep q23
+  w += dpp_f64<0x124>(w);                                                  // row_ror:4  (lane j <- j - 4: the same j & 3)
+  w += dpp_f64<0x128>(w);                                                  // row_ror:8
+  return w;
+}
 __device__ inline double row_min(double v) {
   v = fmin(v, dpp_f64<0xB1>(v));
   v = fmin(v, dpp_f64<0x4E>(v));
@@ -928,15 +957,20 @@ __device__ inline void back_substitute(const d4 (&U)[(NT + NY) * (NT + NY)], int
   }
 #pragma unroll
   for (int pa = L - 1; pa >= 0; --pa) {
-    double vt[4];
+    double vt[4], pt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      double pt = 0.0;
+      pt[t] = 0.0;
 #pragma unroll
-      for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
-      pt = row_sum(pt);                                  // sum over the row's 16 lanes (columns of the tile row)
-      vt[t] = row_bcast64<kRC>(U[pa * NB + L][t]) - pt;   // forward-eliminated rhs minus the already solved blocks
+      for (int pb = pa + 1; pb < NB; ++pb) pt[t] = fma(U[pa * NB + pb][t], xb[pb], pt[t]);
     }
+    // the four row sums (over the row's 16 lanes = the columns of the tile row) as ONE transposed butterfly: lane j gets the sum of pt[j & 3],
+    // four row broadcasts hand every lane all four -- 31 VALU instructions where four plain butterflies take 48
+    const double ws = row_sum4_scatter(pt[0], pt[1], pt[2], pt[3]);
+    vt[0] = row_bcast64<kRC>(U[pa * NB + L][0]) - row_bcast64<0>(ws);   // forward-eliminated rhs minus the already solved blocks
+    vt[1] = row_bcast64<kRC>(U[pa * NB + L][1]) - row_bcast64<1>(ws);
+    vt[2] = row_bcast64<kRC>(U[pa * NB + L][2]) - row_bcast64<2>(ws);
+    vt[3] = row_bcast64<kRC>(U[pa * NB + L][3]) - row_bcast64<3>(ws);
     double q = 0.0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);  // (-T^-1) v, summed over this lane's 4 rows
@@ -986,15 +1020,19 @@ __device__ inline void solve_second_rhs(const d4 (&U)[(NT + NY) * (NT + NY)], in
 #pragma unroll
   for (int pa = L; pa >= 0; --pa) {  // backward, as back_substitute() but with the rhs read from LDS
     const double* rsrc = pa < NT ? rbuf_x + 16 * pa : rbuf_y + 16 * (pa - NT);
-    double vt[4];
+    double vt[4], pt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      double pt = 0.0;
+      pt[t] = 0.0;
 #pragma unroll
-      for (int pb = pa + 1; pb < NB; ++pb) pt = fma(U[pa * NB + pb][t], xb[pb], pt);
-      if (pa < L) pt = row_sum(pt);
-      vt[t] = rsrc[g + 4 * t] - pt;
+      for (int pb = pa + 1; pb < NB; ++pb) pt[t] = fma(U[pa * NB + pb][t], xb[pb], pt[t]);
     }
+    if (pa < L) {   // (as in back_substitute: one transposed butterfly for the four row sums)
+      const double ws = row_sum4_scatter(pt[0], pt[1], pt[2], pt[3]);
+      pt[0] = row_bcast64<0>(ws); pt[1] = row_bcast64<1>(ws); pt[2] = row_bcast64<2>(ws); pt[3] = row_bcast64<3>(ws);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vt[t] = rsrc[g + 4 * t] - pt[t];
     double q = 0.0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) q = fma(U[pa * NB + pa][t], vt[t], q);
@@ -1663,11 +1701,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     const int lane = lane_id();
     const int g = lane >> 4, j = lane & 15;
 
-    const double* Jp = QPL ? nullptr : (const double*)ka->J + p * ka->J_stride;
-    const double* rg = QPL ? nullptr : (const double*)ka->r + p * ka->r_stride;
-    double* vp = (double*)ka->vars + p * ka->vars_stride;
-    const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
-    const double lam = (!QPL && lam_in > 0.0) ? lam_in : 0.0;  // a given G already carries the LM damping
+    // (per-problem addresses -- J, r, A_eq, vars, records, the parked-tile scratch -- are formed from the kernarg block WHERE they are used,
+    // a few scalar instructions each: carried in SGPRs across the pass loop they were spilled to VGPR lanes, i.e. v_readlane / v_writelane
+    // work on the datapath the passes are bound by)
 
     // ---- constants of the problem
     int cvar[MC]; double ca[MC], cb[MC];  // constraint lane + 64 ci
@@ -1681,7 +1717,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
         cb[ci] = ((const double*)ka->cons_b)[p * ka->cons_stride + ix];
       }
     }
-    const double* const Ap = k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr;
     // CLDS: every phase that computes with the constraint data fetches its registers from LDS first (all of them are overwritten, so
     // nothing of them is live across the factorisation or the corrector's second solve) and writes s / z back when it changed them.
     double cs[MC], cz[MC];
@@ -1739,6 +1774,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
       for (int c = 0; c < NT; ++c) xq[c] = 0.0;
       if (iterate_mode || ka->sp.initial_guess_method == MO_GUESS_USER_PROVIDED) {  // qp.cc:440-442
+        const double* const vp = (const double*)ka->vars + p * ka->vars_stride;
         ldv_n<NT, QPL>(vp, j, nn, xq);
 #pragma unroll
         for (int q = 0; q < NY; ++q)
@@ -1765,7 +1801,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     int term = MO_MAX_ITERATIONS, it = 0;
     double mu = iterate_mode ? (ka->mu ? ((const double*)ka->mu)[p * ka->mu_stride] : 0.0) : ka->sp.initial_mu;
     bool guess_pass = !iterate_mode && ka->sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED;
-    double* iter_out = ka->iterations ? (double*)ka->iterations + (size_t)p * ka->sp.max_iterations * MO_ITER_RECORD : nullptr;
+    auto records_of = [&](KArgs kq) -> double* {   // this problem's iteration records (NULL: the caller wants none)
+      return kq->iterations ? (double*)kq->iterations + (size_t)p * kq->sp.max_iterations * MO_ITER_RECORD : nullptr;
+    };
 
     // s = max(1e-9, a x + b), z = 1/s after clamping x into the feasible region in constraint order (qp.cc:464-481)
     auto clamp_and_init_slacks = [&](int lane, int g, int j) {   // on the x that xs holds; leaves the clamped x in xs and xp
@@ -1835,8 +1873,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
     double* const park = reinterpret_cast<double*>(smem);             // PARK_LDS tiles (256 doubles each, lane-linear), then c (V16, N doubles)
     double* const cpark = park + PARK_LDS * 256;
     // the tiles that do not fit: global scratch of this wave's slot in the persistent grid (plan-owned; NULL: re-stream / re-load every pass)
-    double* const Gt = (PARK_GLOBAL > 0 && ka->G_out) ? (double*)ka->G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)ka->G_out_stride : nullptr;
-    const bool can_park = PARK_GLOBAL == 0 || Gt != nullptr;
+    auto tile_scratch_of = [&](KArgs kq) -> double* {
+      return (PARK_GLOBAL > 0 && kq->G_out) ? (double*)kq->G_out + ((size_t)blockIdx.x * WAVES + wave) * (size_t)kq->G_out_stride : nullptr;
+    };
+    const bool can_park = PARK_GLOBAL == 0 || ka->G_out != nullptr;
     bool tiles_cached = false;
     // Lanes whose J piece lies beyond the row never receive DMA data and must read zeros from the ring: a problem that parked tiles there
     // leaves it dirty, so streams that rely on the zeros (n below the grid, flat / gather pieces) clear it again first.
@@ -1862,14 +1902,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       JStream<NT, D, JMODE, NY> stream;
       const bool build_now = __builtin_amdgcn_readfirstlane((int)!tiles_cached) != 0;          // wave-uniform, and hipcc must know it
       const bool stream_now = !QPL && build_now;
+      double* const Gt = tile_scratch_of(ka);
       if (stream_now) {
+        const double* const Jp = (const double*)ka->J + p * ka->J_stride;
+        const double* const rg = (const double*)ka->r + p * ka->r_stride;
         stream.init(Jp, rg, smem, ring_base, lane, g, j, m_r, nn, ka->J_row_major ? (long long)ka->J_ld : 1ll, ka->J_row_major ? 1ll : (long long)ka->J_ld);
         stream.prologue();
       }
       d4 U[NB * NB];
 #pragma unroll
       for (int q = 0; q < NB * NB; ++q) U[q] = d4{0.0, 0.0, 0.0, 0.0};
-      load_a_tiles<NT, QPL, NY>(Ap, ka->A_ld, k, nn, g, j, U);
+      load_a_tiles<NT, QPL, NY>(k > 0 ? (const double*)ka->A + p * ka->A_stride : nullptr, ka->A_ld, k, nn, g, j, U);
       // (xs / xp / ysm hold the state, see above); zero the per-variable scatter arrays
       if (lane < N / 2) {
         azS[2 * lane] = 0.0; azS[2 * lane + 1] = 0.0;
@@ -1890,6 +1933,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
         for (int c = 0; c < NT; ++c) cpart[c] = 0.0;
         stream.run(U, cpart);
+        const double lam_in = ka->lambda_vec ? ((const double*)ka->lambda_vec)[p * ka->lambda_vec_stride] : ka->lambda;
+        const double lam = lam_in > 0.0 ? lam_in : 0.0;   // (J-level input; a given G already carries the LM damping)
 #pragma unroll
         for (int c = 0; c < NT; ++c) {  // G = J^T J + lambda I (nonlinear.cc:187-189): lambda is part of G in the residual too
 #pragma unroll
@@ -1971,14 +2016,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           for (int t = 0; t < 4; ++t) acc1[b] = fma(U[ra * NB + b][t], vR[t], acc1[b]);
         }
         if (ra < NT) {
+          double pt[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            double pt = 0.0;
+            pt[t] = 0.0;
 #pragma unroll
-            for (int b = ra + 1; b < NB; ++b) pt = fma(U[ra * NB + b][t], b < NT ? xv[b] : -yv[b < NT ? 0 : b - NT], pt);  // yv is zero on lanes beyond k
-            pt = row_sum(pt);
-            if (j == 0) tmp[16 * ra + g + 4 * t] = pt;
+            for (int b = ra + 1; b < NB; ++b) pt[t] = fma(U[ra * NB + b][t], b < NT ? xv[b] : -yv[b < NT ? 0 : b - NT], pt[t]);  // yv is zero on lanes beyond k
           }
+          // four row sums as one transposed butterfly (27 VALU instead of 48): lane j of each row holds the sum for row g + 4 (j & 3)
+          const double ws = row_sum4_scatter(pt[0], pt[1], pt[2], pt[3]);
+          if (j < 4) tmp[16 * ra + g + 4 * j] = ws;
         }
         // One tile row at a time: the empty asm statements pin the partial sums of this row HERE.  hipcc otherwise sinks the whole chains of
         // the y columns (acc1[NT ..]) to their use behind the loop and keeps the row operands of ALL tile rows alive until then -- 32 registers
@@ -2066,6 +2113,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
           }
         }
         if (it >= ka->sp.max_iterations) stop = true;                    // MAX_ITERATIONS, qp.cc:149
+        double* const iter_out = records_of(ka);
         if (iter_out) {                                              // wave-uniform
           // The records want NORMS: kkt_after of the previous iteration (lanes 0-3) and kkt_prev of this one (lanes 4-7, qp.cc:118) take
           // ONE lane-parallel f64 square root (~25 VALU instructions) instead of eight wave-wide ones.
@@ -2306,6 +2354,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
       for (int ci = 0; ci < MC; ++ci) { cs[ci] = fma(dsv[ci], ap, cs[ci]); cz[ci] = fma(dzv[ci], ad, cz[ci]); }
       cons_store_state(lane);
       mu_used = mu;
+      double* const iter_out = records_of(ka);
       if (iter_out && lane == 0) {   // IPIterationOutputs of this iteration (structs.hpp:53-64); its KKT norms follow at the next decision point
         double* rec = iter_out + (size_t)it * MO_ITER_RECORD;
         rec[8] = ip_mu; rec[9] = ap; rec[10] = ad;
@@ -2341,6 +2390,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_solve_kernel(const K
 #pragma unroll
     for (int q = 0; q < NY; ++q) yv[q] = ysm[16 * q + j];
     cons_load(lane);
+    double* const vp = (double*)ka->vars + p * ka->vars_stride;
     if (!residual_mode) {  // the state is an input only there
       for (int i = lane; i < nn; i += 64) vp[i] = xs[i];   // x, natural order
       if (g == 0) {

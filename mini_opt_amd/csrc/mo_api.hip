@@ -43,7 +43,7 @@ struct mo_plan {
   // mo_plan_create, for every launch shape the plan can produce (the full system and the k = m = 0 system of mo_linearize / mo_fill_qp);
   // launches only read these three fields -- no allocation, no synchronisation, nothing plan-owned changes on the launch path.
   void* H_work;
-  long long H_work_stride;  // elements per workgroup slot
+  size_t H_work_slot_bytes; // bytes per workgroup slot (also the eigenvalue kernel's n x n fp64 matrix beyond the LDS)
   long long H_work_slots;   // workgroup slots allocated: a launch's grid is clamped to it
   void* tile_scratch;  // fused Solve: per wave slot of the persistent grid, the G tiles a wave cannot park in LDS between passes
   unsigned long long* ticket;  // device work counter of the fused kernels (zeroed on the stream before each launch)
@@ -147,9 +147,9 @@ int launch_chosen(const mo_plan* plan, const mo::KernelArgs& a_in, KernelChoice 
       const size_t need = mo::generic_large_lds_bytes(a, plan->elem);
       if (need > 160 * 1024)
         return fail(MO_ERR_UNSUPPORTED, "n = %d, k = %d, m = %d: not even the state / residual vectors of one problem fit the 160 KiB of LDS", a.n, a.k, a.m);
-      if (!plan->H_work || (long long)mo::generic_large_workspace_elems(a) > plan->H_work_stride)
+      if (!plan->H_work || mo::generic_large_workspace_elems(a) * plan->elem > plan->H_work_slot_bytes)
         return fail(MO_ERR_UNSUPPORTED, "the plan owns no H workspace for n = %d, k = %d (created for n = %d, k = %d)", a.n, a.k, plan->desc.n, plan->desc.k);
-      a.H_work = plan->H_work; a.H_work_stride = plan->H_work_stride; a.H_work_slots = plan->H_work_slots;
+      a.H_work = plan->H_work; a.H_work_stride = (long long)(plan->H_work_slot_bytes / plan->elem); a.H_work_slots = plan->H_work_slots;
     }
     MO_HIP_CHECK(mo::launch_generic(a, plan->desc.dtype, plan->num_cus, s));
   }
@@ -249,7 +249,7 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   p->c_scratch = nullptr;
   p->tile_scratch = nullptr;
   p->H_work = nullptr;
-  p->H_work_stride = 0;
+  p->H_work_slot_bytes = 0;
   p->H_work_slots = 0;
   p->ticket = nullptr;
   if (hipMalloc((void**)&p->ticket, 256) != hipSuccess) {
@@ -265,24 +265,35 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
   // sizes it is known here (shape, dtype, CU count), so it is allocated now -- for the larger of the two systems a plan launches there, the
   // full one and the k = m = 0 one of mo_linearize / mo_fill_qp (fewer LDS bytes per workgroup, hence possibly MORE workgroups per CU) --
   // and never touched again.  max_batch > 0 bounds the number of slots (a launch's grid never exceeds its batch).
-  if (mo::generic_needs_large(a, p->elem)) {
+  // (mo_qp_eigenvalue_stats keeps its n x n fp64 matrix in the same slots once it exceeds the LDS, n > ~139)
+  if (mo::generic_needs_large(a, p->elem) || mo::eig_needs_global(desc->n)) {
     mo::KernelArgs lin = a;
     lin.k = 0; lin.m = 0;
-    long long slots = mo::generic_large_grid(a, p->elem, p->num_cus);
-    if (desc->m_r > 0 && mo::generic_needs_large(lin, p->elem)) {
-      const long long ls = mo::generic_large_grid(lin, p->elem, p->num_cus);
-      if (ls > slots) slots = ls;
+    long long slots = 0;
+    size_t slot_bytes = 0;
+    if (mo::generic_needs_large(a, p->elem)) {
+      slots = mo::generic_large_grid(a, p->elem, p->num_cus);
+      if (desc->m_r > 0 && mo::generic_needs_large(lin, p->elem)) {
+        const long long ls = mo::generic_large_grid(lin, p->elem, p->num_cus);
+        if (ls > slots) slots = ls;
+      }
+      slot_bytes = mo::generic_large_workspace_elems(a) * p->elem;   // (n + k) x ld: covers the n x ld(n) of the k = 0 system
+    }
+    if (mo::eig_needs_global(desc->n)) {
+      const long long es = mo::eig_grid(desc->n, p->num_cus);
+      if (es > slots) slots = es;
+      if (mo::eig_workspace_bytes(desc->n) > slot_bytes) slot_bytes = mo::eig_workspace_bytes(desc->n);
     }
     if (desc->max_batch > 0 && slots > desc->max_batch) slots = desc->max_batch;
-    const size_t per_wg = mo::generic_large_workspace_elems(a);   // (n + k) x ld: covers the n x ld(n) of the k = 0 system
-    const size_t bytes = (size_t)slots * per_wg * p->elem;
+    slot_bytes = (slot_bytes + 255) & ~(size_t)255;
+    const size_t bytes = (size_t)slots * slot_bytes;
     if (hipMalloc(&p->H_work, bytes) != hipSuccess) {
       (void)hipGetLastError();
       (void)hipFree(p->ticket);
       delete p;
       return fail(MO_ERR_HIP, "hipMalloc of the %zu B workspace of H (n = %d, k = %d: %lld workgroup slots) failed", bytes, desc->n, desc->k, slots);
     }
-    p->H_work_stride = (long long)per_wg;
+    p->H_work_slot_bytes = slot_bytes;
     p->H_work_slots = slots;
   }
 
@@ -439,6 +450,23 @@ int mo_kkt_residual(mo_plan* plan, const mo_problem* prob, int64_t batch, const 
   a.mu = mu; a.mu_stride = mu_stride;
   a.r_out = r_out; a.r_out_stride = r_stride; a.kkt_out = kkt_out;
   return launch(plan, a, stream);
+}
+
+int mo_qp_eigenvalue_stats(mo_plan* plan, const mo_problem* prob, int64_t batch, void* out, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_plan(plan)) return rc;
+  if (!out) return fail(MO_ERR_INVALID_ARGUMENT, "out is NULL");
+  mo_plan tmp = *plan;
+  tmp.desc.k = 0; tmp.desc.m = 0;   // only the cost (G, or J with its damping) takes part
+  mo::KernelArgs a;
+  if (int rc = fill_problem(&tmp, prob, batch, true, false, &a)) return rc;
+  if (batch == 0) return MO_OK;
+  if (mo::eig_lds_bytes(plan->desc.n, false) > 160 * 1024)
+    return fail(MO_ERR_UNSUPPORTED, "n = %d: not even the vectors of the tridiagonal eigenvalue problem fit the 160 KiB of LDS", plan->desc.n);
+  MO_HIP_CHECK(hipSetDevice(plan->desc.device));
+  MO_HIP_CHECK(mo::launch_qp_eig(a, plan->desc.dtype, plan->num_cus, out, 3, plan->H_work, plan->H_work_slot_bytes, plan->H_work_slots,
+                                 (hipStream_t)stream));
+  return MO_OK;
 }
 
 int mo_newton_step(mo_plan* plan, const mo_problem* prob, int64_t batch, const void* vars, int64_t vars_stride,
@@ -649,6 +677,7 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
   if (!np->vars || !np->candidate || !np->J || !np->r || !np->r_cand) return fail(MO_ERR_INVALID_ARGUMENT, "vars / candidate / J / r / r_cand is NULL");
   if (d.k > 0 && (!np->J_eq || !np->r_eq || !np->r_eq_cand)) return fail(MO_ERR_DIMENSION, "k = %d but J_eq / r_eq / r_eq_cand is NULL", d.k);
   if (d.m > 0 && (!np->cons_var || !np->cons_a || !np->cons_b)) return fail(MO_ERR_INVALID_ARGUMENT, "m = %d but constraint arrays are NULL", d.m);
+  if (prm->log_qp_eigenvalues && !np->qp_eigenvalues) return fail(MO_ERR_INVALID_ARGUMENT, "log_qp_eigenvalues needs the qp_eigenvalues buffer");
   if (!termination) return fail(MO_ERR_INVALID_ARGUMENT, "termination is NULL");
   if (batch == 0) return MO_OK;
   MO_HIP_CHECK(hipSetDevice(d.device));
@@ -770,6 +799,15 @@ int mo_nls_solve(mo_plan* plan, const mo_nls_problem* np, int64_t batch, const m
       if (np->qp_lagrange && k > 0)
         MO_HIP_CHECK(hipMemcpyAsync((double*)np->qp_lagrange + (size_t)iter * (size_t)batch * 2, lagrange, sizeof(double) * 2 * (size_t)batch,
                                     hipMemcpyDeviceToDevice, s));
+    }
+    if (prm->log_qp_eigenvalues) {   // qp_.ComputeEigenvalueStats() of this iteration's QP (nonlinear.cc:138), still-active problems only
+      mo_plan tmp = *plan;
+      tmp.desc.k = 0; tmp.desc.m = 0;
+      mo::KernelArgs ka;
+      if (int rc = fill_problem(&tmp, &qp, batch, true, false, &ka)) return rc;
+      ka.skip = si + mo::NLS_SI_TERM; ka.skip_stride = mo::NLS_SI;
+      MO_HIP_CHECK(mo::launch_qp_eig(ka, d.dtype, plan->num_cus, (double*)np->qp_eigenvalues + (size_t)iter * (size_t)batch * 3, 3, plan->H_work,
+                                     plan->H_work_slot_bytes, plan->H_work_slots, s));
     }
     MO_HIP_CHECK(mo::launch_cost_derivative(da, d.dtype, s));
     MO_HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(int), s));

@@ -81,6 +81,15 @@ int generic_large_grid(const KernelArgs& a, int elem_size, int num_cus);
 hipError_t launch_nullspace(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream);
 size_t nullspace_lds_bytes(int n, int k, int m_r, int elem_size);
 
+// QP::ComputeEigenvalueStats (qp.cc:12-16): {min, max, min |.|} of the eigenvalues of sym(G) per problem, eig_kernels.hip.  `work`: the plan's
+// global workspace (one slot of work_slot_bytes per workgroup) for matrices beyond the LDS; out [batch][3] in the plan's dtype.
+bool eig_needs_global(int n);
+size_t eig_workspace_bytes(int n);
+size_t eig_lds_bytes(int n, bool matrix_in_lds);
+int eig_grid(int n, int num_cus);
+hipError_t launch_qp_eig(const KernelArgs& a, int dtype, int num_cus, void* out, long long out_stride, void* work, size_t work_slot_bytes,
+                         long long work_slots, hipStream_t stream);
+
 // fused single-wave MFMA kernels for fixed shapes, kkt_fused.hip.  Returns false if (shape, layout) is unsupported.
 bool fused_supported(const KernelArgs& a, int dtype);
 const char* fused_name(const KernelArgs& a, int dtype);

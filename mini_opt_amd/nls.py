@@ -60,13 +60,14 @@ class Params:
     lambda_decrease_on_restore: float = 0.8
     max_lambda: float = 1.0
     min_lambda: float = 0.0
+    log_qp_eigenvalues: bool = False   # nonlinear.hpp:122-123: record the QPEigenvalues of every iteration's QP Hessian
 
     def as_struct(self, retraction: int = L.MO_RETRACT_EUCLIDEAN) -> L.NlsParams:
         p = L.NlsParams()
         L.lib().mo_default_nls_params(C.byref(p))
         for name, _ in L.NlsParams._fields_:
             if hasattr(self, name):
-                setattr(p, name, getattr(self, name))
+                setattr(p, name, int(getattr(self, name)) if name == "log_qp_eigenvalues" else getattr(self, name))
         p.retraction = int(retraction)   # the Retraction is a constructor argument of the solver (nonlinear.hpp:127), not a Param
         return p
 
@@ -192,6 +193,7 @@ class NLSSolverOutputs:
     status: torch.Tensor             # [B] int32 QP status of a problem that ended with QP_FAILURE
     qp_iterations: Optional[torch.Tensor] = None   # [max_iterations, B, max_qp_iterations, 14] QPInteriorPointIteration records (on request)
     qp_lagrange: Optional[torch.Tensor] = None     # [max_iterations, B, 2] {min, l_infinity} of each QP's multipliers (k > 0, on request)
+    qp_eigenvalues: Optional[torch.Tensor] = None  # [max_iterations, B, 3] QPEigenvalues {min, max, abs_min} (Params.log_qp_eigenvalues)
     null_space_path: bool = False                  # equality-only problems: the QP of every iteration is QPNullSpaceSolver's
 
     def NumQPIterations(self) -> torch.Tensor:
@@ -342,10 +344,14 @@ class ConstrainedNonlinearLeastSquares:
             if self.k:
                 qp_lag = torch.full((max(params.max_iterations, 1), B, 2), float("nan"), dtype=torch.float64, device=dev)
                 prob.qp_lagrange = _ptr(qp_lag)
+        qp_eig = None
+        if params.log_qp_eigenvalues:   # NLSIteration::qp_eigenvalues (structs.hpp:267-310), NaN where a problem never ran the iteration
+            qp_eig = torch.full((max(params.max_iterations, 1), B, 3), float("nan"), dtype=torch.float64, device=dev)
+            prob.qp_eigenvalues = _ptr(qp_eig)
         self._callback_error = None
         self._iter_done = 0
         null_path = bool(L.lib().mo_plan_nls_uses_nullspace(self._plan.h))   # the C side's own predicate (shape AND kernel capacity)
-        self._outputs_view = NLSSolverOutputs(term, nit, its, status, qp_its, qp_lag, null_path)
+        self._outputs_view = NLSSolverOutputs(term, nit, its, status, qp_its, qp_lag, qp_eig, null_path)
         cb = L.NLS_EVAL_FN(self._eval)
         rc = L.lib().mo_nls_solve(self._plan.h, C.byref(prob), B, C.byref(sp), cb, None, _ptr(term), _ptr(nit), _ptr(its),
                                   _ptr(status), _stream())

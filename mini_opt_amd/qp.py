@@ -79,6 +79,10 @@ class BatchedQP:
     def V(self) -> int:
         return self.n + 2 * self.m + self.k
 
+    def ComputeEigenvalueStats(self) -> torch.Tensor:
+        """QP::ComputeEigenvalueStats (qp.hpp:122-123): [B, 3] = QPEigenvalues {min, max, abs_min} of the Hessian of every QP of the batch."""
+        return eigenvalue_stats(self)
+
     def _any(self) -> torch.Tensor:
         for t in (self.J, self.G):
             if t is not None:
@@ -345,6 +349,24 @@ class QPNullSpaceSolver:
 
     def variables(self) -> torch.Tensor:
         return self.x_
+
+
+def eigenvalue_stats(problem: BatchedQP) -> torch.Tensor:
+    """QP::ComputeEigenvalueStats (qp.hpp:122-123, qp.cc:12-16) for every QP of the batch: [B, 3] = QPEigenvalues {min, max, abs_min} of the
+    Hessian -- sym(G) from the lower triangle of (G, c) input, or J^T J + lambda I for (J, r, lambda) input."""
+    lib = L.lib()
+    ref = problem.J if problem.J is not None else problem.G
+    B = int(ref.shape[0])
+    desc = L.PlanDesc(problem.n, 0, 0, problem.m_r, _DT[problem.dtype], ref.device.index or 0, L.EXTRA_PLAN_FLAGS, 0, B)
+    plan = C.c_void_p()
+    L.check(lib.mo_plan_create(C.byref(desc), C.byref(plan)))
+    try:
+        out = torch.empty(B, 3, dtype=problem.dtype, device=ref.device)
+        prob = problem.as_struct()   # (only the cost part is read)
+        L.check(lib.mo_qp_eigenvalue_stats(plan, C.byref(prob), B, _ptr(out), _stream()))
+        return out
+    finally:
+        lib.mo_plan_destroy(plan)
 
 
 def linearize(problem: BatchedQP, force_generic: bool = False):

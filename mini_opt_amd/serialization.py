@@ -6,7 +6,7 @@ of a batched solve, with the reference's keys and enum strings, so that tooling 
                      "qp_outputs": {"termination_state": ..., "iterations": [{"kkt_initial": {...}, "kkt_final": {...}, "ip_outputs": {...}}],
                                     "lagrange_multipliers": null | {"min": ..., "l_infinity": ...}}   -- or "SUCCESS" / "NOT_POSITIVE_DEFINITE"
                                                                                                          for the null-space solver (:89-101)
-                     "qp_eigenvalues": null, "directional_derivatives": {"d_f": ..., "d_equality": ...}, "penalty": ...,
+                     "qp_eigenvalues": null | {"min": ..., "max": ..., "abs_min": ...}, "directional_derivatives": {"d_f": ..., "d_equality": ...}, "penalty": ...,
                      "step_result": "SUCCESS", "line_search_steps": [{"alpha": ..., "errors": {"f": ..., "equality": ...}}]}]}
 
 The per-iteration QP records exist only when the solve was run with record_qp_iterations=True; otherwise "iterations" of qp_outputs is
@@ -51,6 +51,7 @@ def nls_outputs_to_json(outputs, problem: int) -> Dict[str, Any]:
     recs = outputs.iterations[p].cpu().numpy()
     qp_recs = None if outputs.qp_iterations is None else outputs.qp_iterations[:, p].cpu().numpy()
     qp_lag = None if outputs.qp_lagrange is None else outputs.qp_lagrange[:, p].cpu().numpy()
+    qp_eig = None if getattr(outputs, "qp_eigenvalues", None) is None else outputs.qp_eigenvalues[:, p].cpu().numpy()
     its: List[Dict[str, Any]] = []
     for i in range(int(outputs.num_iterations[p])):
         r = recs[i]
@@ -71,7 +72,9 @@ def nls_outputs_to_json(outputs, problem: int) -> Dict[str, Any]:
             if qp_recs is None:
                 qp_out["num_iterations"] = nqp
         its.append({"iteration": i, "optimizer_state": OPTIMIZER_STATE[int(r[0])], "lambda": _num(r[1]),
-                    "errors_initial": {"f": _num(r[2]), "equality": _num(r[3])}, "qp_outputs": qp_out, "qp_eigenvalues": None,
+                    "errors_initial": {"f": _num(r[2]), "equality": _num(r[3])}, "qp_outputs": qp_out,
+                    "qp_eigenvalues": None if qp_eig is None or math.isnan(qp_eig[i][0]) else       # std::optional<QPEigenvalues>, serialization.cc:66
+                    {"min": _num(qp_eig[i][0]), "max": _num(qp_eig[i][1]), "abs_min": _num(qp_eig[i][2])},
                     "directional_derivatives": {"d_f": _num(r[4]), "d_equality": _num(r[5])}, "penalty": _num(r[6]),
                     "step_result": STEP_RESULT[0 if math.isnan(r[7]) else int(r[7])], "line_search_steps": steps})
     return {"termination_state": NLS_TERMINATION[term], "iterations": its}

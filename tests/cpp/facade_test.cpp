@@ -171,6 +171,40 @@ static void TestNlsRosenbrock() {
   EXPECT_TRUE(threw);
 }
 
+// QP::ComputeEigenvalueStats (qp.hpp:122-123, qp.cc:12-16) and Params::log_qp_eigenvalues (nonlinear.hpp:122-123, nonlinear.cc:138): the reference
+// has no test of its own for either; the expected values are closed forms (a diagonal G, 2 x 2 matrices read from their LOWER triangle as
+// SelfAdjointEigenSolver does, and J^T J of the Rosenbrock residual at the starting point).
+static void TestEigenvalueStats() {
+  QP qp;
+  BuildQuadratic({{2.0, 1.0}, {-0.5, 3.0}, {3.0, -1.0}, {1.5, 0.0}}, &qp);     // G = diag(4, 0.25, 9, 2.25)
+  QPEigenvalues e = qp.ComputeEigenvalueStats();
+  EXPECT_NEAR(0.25, e.min, 1e-13); EXPECT_NEAR(9.0, e.max, 1e-13); EXPECT_NEAR(0.25, e.abs_min, 1e-13);
+  QP q2(2);
+  q2.G_at(0, 0) = 1.0; q2.G_at(1, 1) = 1.0; q2.G_at(1, 0) = 2.0; q2.G_at(0, 1) = 777.0;   // the strict upper triangle is never read
+  e = q2.ComputeEigenvalueStats();
+  EXPECT_NEAR(-1.0, e.min, 1e-13); EXPECT_NEAR(3.0, e.max, 1e-13); EXPECT_NEAR(1.0, e.abs_min, 1e-13);
+  // the SQP loop records them per outer iteration: G = J^T J (lambda = 0 at the start) of Rosenbrock at (x0, x1): [[1 + 400 x0^2, -200 x0], [., 100]]
+  const std::vector<double> guesses = {-5, -3, 0.8, -0.3};
+  BatchedConstrainedNonlinearLeastSquares nls(2, 2, 0, {}, RosenbrockHost, 2);
+  BatchedConstrainedNonlinearLeastSquares::Params p{};
+  p.max_iterations = 3; p.max_qp_iterations = 1; p.log_qp_eigenvalues = true;
+  (void)nls.Solve(p, guesses);
+  for (int b = 0; b < 2; ++b) {
+    const auto& its = nls.outputs()[(size_t)b].iterations;
+    EXPECT_TRUE(!its.empty() && its[0].qp_eigenvalues.has_value());
+    if (its.empty() || !its[0].qp_eigenvalues) continue;
+    const double x0 = guesses[2 * b], a = 1.0 + 400.0 * x0 * x0, off = -200.0 * x0, d = 100.0;
+    const double mid = 0.5 * (a + d), rad = std::sqrt(0.25 * (a - d) * (a - d) + off * off);
+    EXPECT_NEAR(mid - rad, its[0].qp_eigenvalues->min, 1e-9 * (mid + rad));
+    EXPECT_NEAR(mid + rad, its[0].qp_eigenvalues->max, 1e-12 * (mid + rad));
+    EXPECT_NEAR(mid - rad, its[0].qp_eigenvalues->abs_min, 1e-9 * (mid + rad));
+  }
+  BatchedConstrainedNonlinearLeastSquares::Params p0{};
+  p0.max_iterations = 2; p0.max_qp_iterations = 1;
+  (void)nls.Solve(p0, guesses);
+  EXPECT_TRUE(!nls.outputs()[0].iterations.empty() && !nls.outputs()[0].iterations[0].qp_eigenvalues.has_value());   // off by default
+}
+
 // TestSphereWithNonlinearEqualityConstraints (nonlinear_test.cc:745-826): cost x (6 variables), x0 x1 = 4, x2 x3 = 9
 static void SphereHost(const double* x, int64_t batch, double* r, double* J, double* r_eq, double* J_eq) {
   for (int64_t p = 0; p < batch; ++p) {
@@ -342,6 +376,7 @@ int main() {
   TestWithFullyConstrainedEqualities();
   TestErrors();
   TestNlsRosenbrock();
+  TestEigenvalueStats();
   TestNlsSphereWithEqualities();
   TestNlsDeviceResiduals();
   TestProblemOfResiduals();

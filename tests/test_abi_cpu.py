@@ -78,7 +78,8 @@ def test_product_never_imports_oracle():
 
 
 def test_only_tests_smoke_and_the_cpu_baseline_leg_touch_the_oracle():
-    """tools/ never imports the oracle; bench.py does so only inside its cpu_baseline leg (skipped by --no-cpu-baseline and at N > 1)."""
+    """tools/ never imports the oracle; bench.py does so only BEHIND its timed region, as the checker of the launch just timed (every rank,
+    on a sample of its own shard) and as the timed CPU baseline (rank 0 at N = 1) -- both skipped by --no-cpu-baseline."""
     import re
     for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
         for f in files:
@@ -86,9 +87,13 @@ def test_only_tests_smoke_and_the_cpu_baseline_leg_touch_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"(from|import)\s+oracle", txt), (dirpath, f)
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    assert bench.count("from oracle import") == 1   # "from oracle import oracle as orc"
-    guard = bench.index("if info.world_size > 1 or args.no_cpu_baseline:")
-    assert guard < bench.index("from oracle import oracle")
+    assert bench.count("from oracle import") == 2   # "from oracle import oracle as orc": the checker leg and the cpu_baseline leg
+    timed_region_end = bench.index("elapsed = time.perf_counter() - t0")
+    checker = bench.index("from oracle import oracle")
+    baseline = bench.index("from oracle import oracle", checker + 1)
+    assert timed_region_end < checker < baseline                       # never inside what is measured
+    assert bench.index("if not args.dry and not args.no_cpu_baseline:") < checker
+    assert checker < bench.index("if info.world_size > 1 or args.no_cpu_baseline:") < baseline
 
 
 def test_ctypes_mirrors_match_the_header_layout(tmp_path):

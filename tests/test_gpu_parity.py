@@ -57,27 +57,30 @@ def batch_to_device(hb, dt=torch.float64):
 
 # Disagreements with the oracle are counted per TEST (a sweep calls solves_agree_or_knife_edge once per shape with a handful of problems):
 # every one of them needs its logged knife edge, a single call may hold at most one, and over a whole test they may not exceed 5 %.
-_TALLY = {"off": 0, "total": 0}
+_TALLY = {"off": set(), "all": set()}   # distinct problems (a test may hold several kernels to the oracle on the same problems)
 
 
 @pytest.fixture(autouse=True)
 def _knife_edge_budget():
-    _TALLY["off"], _TALLY["total"] = 0, 0
+    _TALLY["off"], _TALLY["all"] = set(), set()
     yield
-    if _TALLY["total"] >= 20:
-        assert _TALLY["off"] <= 0.05 * _TALLY["total"], f"{_TALLY['off']} of {_TALLY['total']} Solves of this test differ from the oracle (each on a knife edge, but more than 5 %)"
+    off, total = len(_TALLY["off"]), len(_TALLY["all"])
+    if total >= 20:
+        assert off <= 0.05 * total, f"{off} of {total} problems of this test have a Solve that differs from the oracle (each on a knife edge, but more than 5 %)"
+    else:
+        assert off <= 1, f"{off} of {total} problems of this test have a Solve that differs from the oracle"
 
 
 KNIFE_EDGE_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "qp_disagreements.jsonl")
 
 
-def solves_agree_or_knife_edge(tag, make_qp, kw, runs, max_fraction=0.05, max_count=1):
+def solves_agree_or_knife_edge(tag, make_qp, kw, runs):
     """`runs` = {label: (termination [B], iterations [B])} of device Solves of the same problems.  EVERY run is held to the oracle's Solve
     (oracle/margins.py replays it with its decision margins): a run whose (termination, iteration count) differs from the oracle's is only
     accepted on a problem where one decision of the ORACLE's run sat nearer to its threshold than the knife-edge threshold of its kind --
     also when the oracle ends in MAX_ITERATIONS (no blanket exemption: the device must then end there too, or show the knife edge).
-    Every accepted disagreement is logged to gpurun_out/qp_disagreements.jsonl.  Returns the mask of problems on which all runs agree
-    with the oracle."""
+    Every accepted disagreement is logged to gpurun_out/qp_disagreements.jsonl; over a whole test at most 5 % of the Solves may be such
+    cases (fixture _knife_edge_budget).  Returns the mask of problems on which all runs agree with the oracle."""
     from oracle import margins as M
     labels = list(runs)
     B = len(runs[labels[0]][0])
@@ -99,8 +102,8 @@ def solves_agree_or_knife_edge(tag, make_qp, kw, runs, max_fraction=0.05, max_co
         with open(KNIFE_EDGE_LOG, "a") as f:
             for row in rows:
                 f.write(json.dumps(row) + "\n")
-    _TALLY["off"] += int((~agree).sum()); _TALLY["total"] += B
-    assert (~agree).mean() <= max_fraction or (~agree).sum() <= max_count, (tag, float((~agree).mean()))
+    base = str(tuple(tag)[:5]) if isinstance(tag, tuple) else str(tag)   # (the budget is per test: the _knife_edge_budget fixture)
+    _TALLY["all"].update((base, p) for p in range(B)); _TALLY["off"].update((base, int(p)) for p in np.flatnonzero(~agree))
     return agree
 
 
