@@ -143,20 +143,17 @@ def plan_workload(args, info):
 
 def launch_ranks(n_ranks: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as CHILDREN through
-    `python -m torch.distributed.run` on 127.0.0.1 with a free port and return the launcher's exit code.  Nothing in this
-    process initialises HIP (no torch import, no device query): the ranks are fresh processes."""
-    import socket
+    `python -m torch.distributed.run --standalone --local-addr 127.0.0.1` (the launcher picks the rendezvous port itself: no
+    bind-close-reuse race on a port number) and return the launcher's exit code.  Nothing in this process initialises HIP (no torch
+    import, no device query): the ranks are fresh processes."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n_ranks}", os.path.abspath(__file__)] + list(argv)
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)   # the ranks' stderr goes straight through
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     for ln in res.stdout.splitlines():

@@ -93,6 +93,8 @@ def build(force: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "mini_opt_hip.h"))
+    srcs.append(os.path.join(CSRC, "Makefile"))
+    srcs.append(os.path.join(_HERE, "..", "tools", "isa_lint.py"))   # the build lints its own listings: a changed lint re-runs it
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)

@@ -747,9 +747,9 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
           bool nz = false;
           for (int i = j + 1 + tid; i < rows; i += kThreads) nz |= !(panel[i + (size_t)j * ldp] == (T)0);
           if (nz || !(d == (T)0)) w.iflag[1] = 1;
-          __syncthreads();
-          if (tid == 0) w.invd[kb + j] = (T)0;
-          if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }
+          if (tid == 0) w.invd[kb + j] = (T)0;                                    // published by the barrier below, together with the flag
+          __syncthreads();                                                         // (the trailing update of a panel whose LAST column is a zero
+          if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }     //  pivot reads invd right behind this loop: no unsynchronised write)
           found_zero = true;
           continue;
         }

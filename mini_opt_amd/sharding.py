@@ -55,19 +55,34 @@ def timing_group(info: RankInfo, want: str, device=None, timeout_s: float = 120.
     import datetime
 
     import torch
+
+    def all_agree(ok: int) -> bool:   # over gloo (the default group): did every rank get this far?
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    # Step 1: every rank creates the group (new_group is collective over the default group and lazy about the communicator), then all
+    # ranks agree over gloo that they have one -- a rank on which creation fails must not leave the others alone in an RCCL collective.
     ok, group, why = 1, None, ""
     try:
         group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+    except Exception as exc:
+        ok, why = 0, repr(exc)[:200]
+    if not all_agree(ok):
+        return None, "gloo (rccl unavailable" + (": " + why if why else " on another rank") + ")", None
+    # Step 2: the probe collective, asynchronous with a bounded wait -- a rank whose communicator cannot form (two ranks on one GPU in a
+    # rehearsal, no IPC between the devices) reports over gloo instead of sitting in the collective until the watchdog aborts the process.
+    try:
         probe = torch.ones(1, device=device)
-        dist.all_reduce(probe, group=group)
+        work = dist.all_reduce(probe, group=group, async_op=True)
+        if not work.wait(timeout=datetime.timedelta(seconds=min(timeout_s, 60.0))):
+            raise RuntimeError("probe all-reduce timed out")
         torch.cuda.synchronize(device)
         if int(probe.item()) != info.world_size:
             raise RuntimeError(f"probe all-reduce returned {probe.item()}")
-    except Exception as exc:  # RCCL unavailable here (e.g. two ranks sharing one GPU in a rehearsal, no IPC between the devices)
+    except Exception as exc:
         ok, why = 0, repr(exc)[:200]
-    flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # over gloo: do all ranks have a working RCCL group?
-    if int(flag.item()) == 1:
+    if all_agree(ok):
         return group, "rccl", device
     return None, "gloo (rccl unavailable" + (": " + why if why else " on another rank") + ")", None
 

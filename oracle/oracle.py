@@ -14,7 +14,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libkkt_oracle.so")
+# MO_ORACLE_LIB: another build of the same source (tests/test_oracle_asan_cpu.py loads libkkt_oracle_asan.so this way)
+_LIB_PATH = os.environ.get("MO_ORACLE_LIB") or os.path.join(_HERE, "libkkt_oracle.so")
 
 ORC_OK, ORC_NONPOSITIVE_SLACK, ORC_FACTORIZATION_FAILED = 0, 1, 2
 COMPLEMENTARITY, FIXED_DECREASE, PREDICTOR_CORRECTOR = 0, 1, 2
@@ -29,7 +30,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile). Building the checker is not using it."""
     src = os.path.join(_HERE, "kkt_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "libkkt_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -16,7 +16,7 @@ for f in mo_api kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_n
       -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -amdgpu-function-calls=false -DMO_TUNING $flags -I"$src" -c "$src/$f.hip" -o "$tmp/$f.o" &
     objs="$objs $tmp/$f.o"
   else
-    objs="$objs $src/$f.o"
+    objs="$objs $src/build/$f.o"
   fi
 done
 wait
