@@ -196,6 +196,12 @@ __device__ inline double rl(double v, int lane) {
 __device__ inline float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// a value every lane holds alike (read from one LDS address), as a scalar: decisions on it become scalar branches instead of EXEC-masked regions
+__device__ inline double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ inline float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline double absT(double v) { return fabs(v); }
 __device__ inline float absT(float v) { return fabsf(v); }
 __device__ inline double sqrtT(double v) { return sqrt(v); }
@@ -654,24 +660,30 @@ __device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
 // a handful of instructions per pivot and row where the first version (panel in LDS, elements dealt out by a flat index) spent an integer
 // division, three LDS reads and an LDS write per ELEMENT.  Same arithmetic (one IEEE division per pivot, the same products in the same
 // order), same zero-pivot rules.  Leaves W = L D in H and in the LDS panel (for the trailing update), 1 / D in invd.  Returns the status.
-template <typename T, int NBR, int RPT>
+// FROM_LDS (the left-looking factorisation): the panel's current values -- H minus the update from every column in front of it -- were
+// staged in the LDS panel by left_update_panel; H itself is only WRITTEN here, once, with the finished W.
+template <typename T, int NBR, int RPT, bool FROM_LDS = false>
 __device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd, int rows, int ldp, int tid, bool& found_zero) {
   T a[RPT][NBR];
 #pragma unroll
   for (int e = 0; e < RPT; ++e) {
     const int i = tid + 256 * e;
 #pragma unroll
-    for (int jj = 0; jj < NBR; ++jj)
-      a[e][jj] = (i < rows && jj < wd && i >= jj) ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
+    for (int jj = 0; jj < NBR; ++jj) {
+      if (FROM_LDS) a[e][jj] = (i < rows && jj < wd && i >= jj) ? panel[i + (size_t)jj * ldp] : (T)0;
+      else a[e][jj] = (i < rows && jj < wd && i >= jj) ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
+    }
   }
+  if (FROM_LDS) __syncthreads();   // the publish buffers below overlay the first elements of the staged panel
   int status = MO_STATUS_OK;
+  int fz = uni((int)found_zero);   // scalar by construction: no decision of the pivot loop may become an EXEC-masked region around a[][]
 #pragma unroll
   for (int j = 0; j < NBR; ++j) {
     if (j >= wd || status != MO_STATUS_OK) continue;                              // (uniform)
     T* const buf = panel + (j & 1) * (NBR + 1);
     if (tid >= j && tid < wd) buf[tid] = a[0][j];
     __syncthreads();
-    const T d = buf[j];                                                           // uniform
+    const T d = uni(buf[j]);                                                      // the pivot, as a scalar
     if (!(absT(d) > (T)0)) {                                                      // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
       bool nz = false;
 #pragma unroll
@@ -680,13 +692,13 @@ __device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd
         nz |= (i > j && i < rows && !(a[e][j] == (T)0));
       }
       if (nz || !(d == (T)0)) w.iflag[1] = 1;
-      __syncthreads();
       if (tid == 0) w.invd[kb + j] = (T)0;
-      if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }
-      found_zero = true;
+      __syncthreads();
+      if (uni(w.iflag[1])) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }
+      fz = 1;
       continue;
     }
-    if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }        // non-zero pivot after a zero pivot
+    if (fz) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }                // non-zero pivot after a zero pivot
     const T inv = (T)1 / d;
     if (tid == 0) w.invd[kb + j] = inv;
 #pragma unroll
@@ -698,6 +710,7 @@ __device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd
     }
   }
   __syncthreads();                                                                // the publish buffers live in the panel region
+  found_zero = fz != 0;
   if (status != MO_STATUS_OK) return status;
 #pragma unroll
   for (int e = 0; e < RPT; ++e) {
@@ -713,118 +726,183 @@ __device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd
   }
   return status;
 }
-// LARGE: right-looking blocked LDL^T with H in global memory (same natural order, same zero-pivot rules, same result layout: W = L D below
-// the diagonal, invd = 1 / D).  Per block column: the panel (all rows below the diagonal block, NB columns) is staged in LDS and factorised
-// there pivot by pivot (one barrier per pivot); the trailing matrix gets its rank-NB update H22 -= W21 D^-1 W21^T straight in global memory
-// (L2-resident), thread (ti, tj) of the 16 x 16 grid owning a 4 x 4 register block of every 64 x 64 tile of the lower triangle.
+// LARGE: LEFT-LOOKING blocked LDL^T with H in global memory (round 4; same natural order, same zero-pivot rules, same result layout: W = L D
+// below the diagonal, invd = 1 / D).  Round 3 was right-looking -- after every 16-column panel the whole trailing matrix was read, updated and
+// written back: P^3 / (6 NB) elements read AND written (4.3 MB per factorisation at P = 296 for 0.35 MB of H), the kernel's largest traffic
+// term.  Left-looking, a block column is brought up to date only when its turn comes:
+//   acc = W[panel rows, 0 .. kb) D^-1 W[kb .. kb + 32, 0 .. kb)^T      on the matrix cores, operands straight from the finished columns of H
+//   panel = H[panel] - acc                                             staged in LDS, 16 columns at a time
+//   the panel is factorised in registers (factor_panel_regs, thread = row) and its W is written to H -- the ONLY write of those elements.
+// Every element of H is written once and read P / 32 times on average: 1.1 MB of reads + 0.35 MB of writes at P = 296.  The outer block is 32
+// columns = two tile columns of accumulators per 16-row strip (a wave owns every fourth strip: 5 strips x 2 tiles x 8 registers at 320 rows);
+// its second half also needs the first half's columns, which it takes from the LDS copy factor_panel_regs leaves behind.  Panels of more than
+// 320 rows fall back to 16 columns and accumulate in chunks of 320 rows.  Tiles are computed transposed (D[jl][il], as the J^T J and the old
+// trailing update did): the lanes of a 16-lane row hold 16 consecutive rows, so every operand load is a whole 128-byte segment of a column.
+constexpr int kLeftSPW = 5;      // 16-row strips per wave and chunk: 4 waves x 5 strips = 320 rows
+// acc[sl][c] += sum over the columns [c_begin, c_end) of SRC of  W[row0 + i][col] inv[col] W[rowc + 16 c + jl][col]   for strip sl of this wave
+// (rows i = 16 (4 sl + wave) + l of the chunk that starts at panel row r0) and tile column c.  SRC: H (global, leading dimension w.ldh, absolute
+// rows) or the LDS copy of the half panel just factorised (leading dimension ldp, rows relative to that panel).
+template <typename T, int C16, bool FROM_PANEL>
+__device__ inline void left_accumulate(const Ws<T>& w, const T* src, int ld, int row_base, int colrow_base, int c_begin, int c_end, int inv_base,
+                                       int rows_avail, int r0, int c_first, int lane, int wave, typename Mfma16<T>::Acc (&acc)[kLeftSPW][C16]) {
+  typedef Mfma16<T> MF;
+  const int g = lane >> 4, l = lane & 15;
+  int irow[kLeftSPW];
+  bool have[kLeftSPW];
+#pragma unroll
+  for (int sl = 0; sl < kLeftSPW; ++sl) {
+    const int i = r0 + 16 * (4 * sl + wave) + l;
+    have[sl] = r0 + 16 * (4 * sl + wave) < rows_avail;           // wave-uniform: the strip exists
+    irow[sl] = row_base + (i < rows_avail ? i : rows_avail - 1);  // clamped (in bounds): results of rows beyond the panel are never stored
+  }
+  int jrow[C16];
+#pragma unroll
+  for (int c = 0; c < C16; ++c) {
+    const int j = 16 * (c_first + c) + l;
+    jrow[c] = colrow_base + (j < rows_avail ? j : rows_avail - 1);
+  }
+#pragma unroll 2
+  for (int q = c_begin; q < c_end; q += 4) {
+    const bool valid = q + g < c_end;
+    const int col = valid ? q + g : c_begin;
+    const T inv = valid ? w.invd[inv_base + col] : (T)0;
+    const T* colp = src + (size_t)col * ld;
+    T aj[C16], bi[kLeftSPW];
+#pragma unroll
+    for (int c = 0; c < C16; ++c) aj[c] = valid ? colp[jrow[c]] * inv : (T)0;
+#pragma unroll
+    for (int sl = 0; sl < kLeftSPW; ++sl) bi[sl] = (valid && have[sl]) ? colp[irow[sl]] : (T)0;
+#pragma unroll
+    for (int sl = 0; sl < kLeftSPW; ++sl) {
+      if (!have[sl]) continue;
+#pragma unroll
+      for (int c = 0; c < C16; ++c) acc[sl][c] = MF::mac(aj[c], bi[sl], acc[sl][c]);
+    }
+  }
+  (void)FROM_PANEL;
+}
+// Stage H[kb + i][kb + 16 c + j] - acc for the rows of this chunk and tile column c into the LDS panel of the half that starts at panel column
+// 16 c (rows relative to that half: i - 16 c), zeros above the diagonal.
+template <typename T, int C16>
+__device__ inline void left_stage(const Ws<T>& w, T* panel, int kb, int rows, int wd, int c, int r0, int lane, int wave,
+                                  const typename Mfma16<T>::Acc (&acc)[kLeftSPW][C16]) {
+  typedef Mfma16<T> MF;
+  const int g = lane >> 4, l = lane & 15;
+  const int ldp = (rows - 16 * c) | 1;
+#pragma unroll
+  for (int sl = 0; sl < kLeftSPW; ++sl) {
+    const int i = r0 + 16 * (4 * sl + wave) + l;                // panel row
+    if (r0 + 16 * (4 * sl + wave) >= rows) continue;            // wave-uniform
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = 16 * c + MF::row(g, t);                     // panel column
+      if (i < rows && i >= 16 * c && j < wd) {
+        const T v = j <= i ? w.H[(size_t)(kb + i) + (size_t)(kb + j) * w.ldh] - acc[sl][c][t] : (T)0;
+        panel[(i - 16 * c) + (size_t)(j - 16 * c) * ldp] = v;
+      }
+    }
+  }
+}
+// One 16-column half panel whose current values sit in the LDS panel: factorise (registers where the rows allow it, LDS otherwise), write W to H.
+template <typename T>
+__device__ inline int left_factor_half(const Ws<T>& w, T* panel, int kb, int wd, int rows, int tid, bool& found_zero) {
+  const int ldp = rows | 1;
+  int status = MO_STATUS_OK;
+  if (uni((int)kThreads) == 256 && rows <= 512) {
+    if (rows <= 256) status = factor_panel_regs<T, 16, 1, true>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+    else status = factor_panel_regs<T, 16, 2, true>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+    __syncthreads();                                                             // the LDS copy of W is read by other threads
+    return status;
+  }
+  for (int j = 0; j < wd; ++j) {                                                 // any size: the panel stays in LDS
+    const T d = uni(panel[j + (size_t)j * ldp]);                                  // the pivot, as a scalar
+    if (!(absT(d) > (T)0)) {                                                      // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
+      bool nz = false;
+      for (int i = j + 1 + tid; i < rows; i += kThreads) nz |= !(panel[i + (size_t)j * ldp] == (T)0);
+      if (nz || !(d == (T)0)) w.iflag[1] = 1;
+      if (tid == 0) w.invd[kb + j] = (T)0;                                        // published by the barrier below, together with the flag
+      __syncthreads();
+      if (uni(w.iflag[1])) { status = MO_STATUS_FACTORIZATION_FAILED; break; }
+      found_zero = true;
+      continue;
+    }
+    if (uni((int)found_zero)) { status = MO_STATUS_FACTORIZATION_FAILED; break; } // non-zero pivot after a zero pivot
+    const T inv = (T)1 / d;
+    if (tid == 0) w.invd[kb + j] = inv;
+    const int rem = wd - j - 1;
+    for (int idx = tid; idx < rem * rows; idx += kThreads) {                      // the panel's remaining columns
+      const int c = idx / rows, i = idx - c * rows, jj = j + 1 + c;
+      if (i >= jj) panel[i + (size_t)jj * ldp] -= panel[i + (size_t)j * ldp] * (panel[jj + (size_t)j * ldp] * inv);
+    }
+    __syncthreads();
+  }
+  if (status != MO_STATUS_OK) return status;                                       // uniform
+  for (int idx = tid; idx < rows * wd; idx += kThreads) {                          // W to H: the one write of these elements
+    const int jj = idx / rows, i = idx - jj * rows;
+    if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = panel[i + (size_t)jj * ldp];
+  }
+  __syncthreads();
+  return status;
+}
 template <typename T>
 __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) {
-  T* const panel = w.Jc;                    // the J chunk is dead by now
+  typedef Mfma16<T> MF;
+  typedef typename MF::Acc Acc;
+  // (the LDS panel region holds NB columns of P | 1 rows, NB = 32 / 16 / 8 by what fits beside the vectors: one 16-column half panel, or
+  // NB = 8 columns of a very large system -- the tiles then carry eight idle columns)
+  T* const panel = w.Jc;                     // the J chunk is dead by now
   bool found_zero = false;
   int status = MO_STATUS_OK;
-  for (int kb = 0; kb < P && status == MO_STATUS_OK; kb += NB) {
-    const int wd = P - kb < NB ? P - kb : NB, rows = P - kb, ldp = rows | 1;
-    if (kThreads == 256 && NB <= 32 && rows <= (NB <= 16 ? 512 : 256)) {         // the panel in registers (uniform)
-      // (one or two rows per thread with 16 columns, one with 32: 32-column panels of more than 256 rows only exist for 256 < n + k <~ 280 with
-      // few constraints, and every further instantiation costs the others registers -- four rows per thread made n = 256 10 % slower)
-      if (NB <= 16) {
-        if (rows <= 256) status = factor_panel_regs<T, 16, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
-        else status = factor_panel_regs<T, 16, 2>(w, panel, kb, wd, rows, ldp, tid, found_zero);
-      } else {
-        status = factor_panel_regs<T, 32, 1>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+  // (the LARGE kernel is launched with exactly four waves: launch_generic_large.  The wave index is made scalar so that the per-strip
+  // conditions below are scalar branches, not EXEC-masked regions around the accumulator tiles.)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int kb = 0;
+  while (kb < P && status == MO_STATUS_OK) {
+    const int rows = P - kb;
+    if (rows <= 64 * kLeftSPW) {
+      // ---- a 32-column outer block in one chunk of rows: both halves' accumulators live in registers
+      const int wd = rows < 32 ? rows : 32;
+      Acc acc[kLeftSPW][2];
+#pragma unroll
+      for (int sl = 0; sl < kLeftSPW; ++sl) { acc[sl][0] = Acc{(T)0, (T)0, (T)0, (T)0}; acc[sl][1] = Acc{(T)0, (T)0, (T)0, (T)0}; }
+      left_accumulate<T, 2, false>(w, w.H, w.ldh, kb, kb, 0, kb, 0, rows, 0, 0, lane, wave, acc);
+      left_stage<T, 2>(w, panel, kb, rows, wd, 0, 0, lane, wave, acc);
+      __syncthreads();
+      status = uni(left_factor_half<T>(w, panel, kb, wd < 16 ? wd : 16, rows, tid, found_zero));
+      if (status != MO_STATUS_OK) break;
+      if (wd > 16) {
+        // second half: the columns of the first half come from its LDS copy (rows relative to the first half's panel)
+        {
+          // tile column 1 only: aj from panel rows 16 .. 31, bi from the strips' rows; columns 0 .. 15 of the LDS panel, inv at kb + column
+          Acc one[kLeftSPW][1];
+#pragma unroll
+          for (int sl = 0; sl < kLeftSPW; ++sl) one[sl][0] = acc[sl][1];
+          left_accumulate<T, 1, true>(w, panel, rows | 1, 0, 0, 0, 16, kb, rows, 0, 1, lane, wave, one);
+#pragma unroll
+          for (int sl = 0; sl < kLeftSPW; ++sl) acc[sl][1] = one[sl][0];
+        }
+        __syncthreads();                                                            // every wave is done with the first half's LDS copy
+        left_stage<T, 2>(w, panel, kb, rows, wd, 1, 0, lane, wave, acc);
+        __syncthreads();
+        status = uni(left_factor_half<T>(w, panel, kb + 16, wd - 16, rows - 16, tid, found_zero));
       }
-      if (status != MO_STATUS_OK) break;                                         // uniform
-      __syncthreads();                                                           // the LDS copy of the panel is read by other threads below
-    } else {                                                                     // any size: the panel in LDS
-      for (int idx = tid; idx < rows * wd; idx += kThreads) {
-        const int jj = idx / rows, i = idx - jj * rows;
-        panel[i + (size_t)jj * ldp] = i >= jj ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
+      kb += wd;
+    } else {
+      // ---- more than 320 rows: a 16-column block (8 where the LDS holds no more), the update accumulated and staged in chunks of 320 rows
+      const int wd = NB < 16 ? NB : 16;
+      for (int r0 = 0; r0 < rows; r0 += 64 * kLeftSPW) {
+        Acc acc[kLeftSPW][1];
+#pragma unroll
+        for (int sl = 0; sl < kLeftSPW; ++sl) acc[sl][0] = Acc{(T)0, (T)0, (T)0, (T)0};
+        left_accumulate<T, 1, false>(w, w.H, w.ldh, kb, kb, 0, kb, 0, rows, r0, 0, lane, wave, acc);
+        left_stage<T, 1>(w, panel, kb, rows, wd, 0, r0, lane, wave, acc);
       }
       __syncthreads();
-      for (int j = 0; j < wd; ++j) {
-        const T d = panel[j + (size_t)j * ldp];                                   // uniform
-        if (!(absT(d) > (T)0)) {                                                  // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
-          bool nz = false;
-          for (int i = j + 1 + tid; i < rows; i += kThreads) nz |= !(panel[i + (size_t)j * ldp] == (T)0);
-          if (nz || !(d == (T)0)) w.iflag[1] = 1;
-          if (tid == 0) w.invd[kb + j] = (T)0;                                    // published by the barrier below, together with the flag
-          __syncthreads();                                                         // (the trailing update of a panel whose LAST column is a zero
-          if (w.iflag[1]) { status = MO_STATUS_FACTORIZATION_FAILED; break; }     //  pivot reads invd right behind this loop: no unsynchronised write)
-          found_zero = true;
-          continue;
-        }
-        if (found_zero) { status = MO_STATUS_FACTORIZATION_FAILED; break; }      // non-zero pivot after a zero pivot
-        const T inv = (T)1 / d;
-        if (tid == 0) w.invd[kb + j] = inv;
-        const int rem = wd - j - 1;
-        for (int idx = tid; idx < rem * rows; idx += kThreads) {                  // the panel's remaining columns
-          const int c = idx / rows, i = idx - c * rows, jj = j + 1 + c;
-          if (i >= jj) panel[i + (size_t)jj * ldp] -= panel[i + (size_t)j * ldp] * (panel[jj + (size_t)j * ldp] * inv);
-        }
-        __syncthreads();
-      }
-      if (status != MO_STATUS_OK) break;                                           // uniform
-      for (int idx = tid; idx < rows * wd; idx += kThreads) {                      // W back to H
-        const int jj = idx / rows, i = idx - jj * rows;
-        if (i >= jj) w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] = panel[i + (size_t)jj * ldp];
-      }
-    }
-    const int tr = rows - wd;                                                    // trailing rows / columns
-    if (tr > 0 && tid < 256) {
-      // H22 -= W21 D^-1 W21^T on the matrix cores, 64 x 64 macro tiles of the lower triangle: wave wv owns the 16 rows I0 + 16 wv .. of a macro
-      // tile and its (up to) four 16 x 16 tiles, each computed transposed (A operand: the column block scaled by 1 / D, B operand: the row
-      // block), so that a 16-lane row holds 16 consecutive rows of H and the read-modify-write moves whole 128-byte segments.  The loads of
-      // H are issued before the products.  Pivots beyond the panel's width contribute zeros (both operands are masked).
-      typedef Mfma16<T> MF;
-      typedef typename MF::Acc Acc;
-      const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, l = lane & 15;
-      for (int I0 = 0; I0 < tr; I0 += 64) {
-        const int ib = I0 + 16 * wv;                                             // first row of this wave's tiles
-        if (ib >= tr) continue;                                                  // (wave-uniform; no barrier inside these loops)
-        const int i = ib + l, irow = wd + (i < tr ? i : tr - 1);
-        for (int J0 = 0; J0 <= I0; J0 += 16 * MO_LARGE_TW) {   // MO_LARGE_TW tiles = one round of workspace latency
-          bool need[MO_LARGE_TW];
-          int jrow[MO_LARGE_TW];
-          Acc acc[MO_LARGE_TW];
-          T hv[MO_LARGE_TW][4];
-#pragma unroll
-          for (int b_ = 0; b_ < MO_LARGE_TW; ++b_) {
-            need[b_] = J0 + 16 * b_ < tr && J0 + 16 * b_ <= ib;                  // exists, and not strictly above the diagonal
-            const int jl = J0 + 16 * b_ + l;
-            jrow[b_] = wd + (jl < tr ? jl : tr - 1);
-            acc[b_] = Acc{(T)0, (T)0, (T)0, (T)0};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int j = J0 + 16 * b_ + MF::row(g, t);
-              hv[b_][t] = (need[b_] && i < tr && j <= i) ? w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] : (T)0;
-            }
-          }
-          for (int q = 0; q < wd; q += 4) {
-            const bool valid = q + g < wd;
-            const int kq = valid ? q + g : 0;
-            const T inv = valid ? w.invd[kb + kq] : (T)0;
-            const T bi = valid ? panel[irow + (size_t)kq * ldp] : (T)0;
-#pragma unroll
-            for (int b_ = 0; b_ < MO_LARGE_TW; ++b_) {
-              if (!need[b_]) continue;
-              const T aj = valid ? panel[jrow[b_] + (size_t)kq * ldp] * inv : (T)0;
-              acc[b_] = MF::mac(aj, bi, acc[b_]);
-            }
-          }
-#pragma unroll
-          for (int b_ = 0; b_ < MO_LARGE_TW; ++b_) {
-            if (!need[b_]) continue;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int j = J0 + 16 * b_ + MF::row(g, t);
-              if (i < tr && j <= i) w.H[(size_t)(kb + wd + i) + (size_t)(kb + wd + j) * w.ldh] = hv[b_][t] - acc[b_][t];
-            }
-          }
-        }
-      }
+      status = uni(left_factor_half<T>(w, panel, kb, wd, rows, tid, found_zero));
+      kb += wd;
     }
     __threadfence_block();
-    __syncthreads();   // the next panel is read by other threads than the ones that wrote it
+    __syncthreads();   // the next block reads columns other threads wrote
   }
   __syncthreads();
   return status;
@@ -1645,6 +1723,9 @@ static hipError_t launch_generic_large(const KernelArgs& a, int dtype, int num_c
 hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream_t stream) {
   const int elem = dtype == MO_F64 ? 8 : 4;
   if (generic_needs_large(a, elem)) return launch_generic_large(a, dtype, num_cus, stream);
+#ifdef MO_GENERIC_LARGE_ONLY   // development builds of the LARGE path alone (a fifth of the translation unit's compile time)
+  return hipErrorInvalidValue;
+#else
   const size_t lds = generic_lds_bytes(a, elem);
 #ifdef MO_TUNING
   static const int env_threads = [] { const char* e = getenv("MO_GENERIC_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob
@@ -1690,6 +1771,7 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
 #undef MO_LAUNCH_FACTORISING
 #undef MO_LAUNCH_GENERIC
   return hipGetLastError();
+#endif
 }
 
 size_t nullspace_lds_bytes(int n, int k, int m_r, int elem_size) {
