@@ -21,6 +21,7 @@
 #include <math.h>
 
 #include <stdlib.h>
+#include <type_traits>
 
 #include "mo_kernels.h"
 
@@ -62,7 +63,7 @@ namespace {
 #endif
 
 #ifdef MO_GENERIC_STAMPS
-__device__ unsigned long long g_nd_stamps[8];   // diagnostic build only: where newton_direction spends its time
+__device__ unsigned long long g_nd_stamps[16];   // diagnostic build only: where newton_direction spends its time
 #define MO_NDSTAMP(i)                                                              \
   do {                                                                             \
     __syncthreads();                                                               \
@@ -72,8 +73,18 @@ __device__ unsigned long long g_nd_stamps[8];   // diagnostic build only: where 
       nd_prev = t__;                                                               \
     }                                                                              \
   } while (0)
+#define MO_FBSTAMP(i)                                                              \
+  do {                                                                             \
+    __syncthreads();                                                               \
+    if (threadIdx.x == 0) {                                                        \
+      const unsigned long long t__ = __builtin_amdgcn_s_memtime();                 \
+      atomicAdd(&g_nd_stamps[i], t__ - fb_prev);                                   \
+      fb_prev = t__;                                                               \
+    }                                                                              \
+  } while (0)
 #else
 #define MO_NDSTAMP(i) do { } while (0)
+#define MO_FBSTAMP(i) do { } while (0)
 #endif
 
 // Workgroup size is chosen at launch: 256 threads (4 waves) for large systems, ONE wave for small ones (n + k <= 48), where a
@@ -117,7 +128,9 @@ __host__ __device__ inline size_t ws_elems(int n, int k, int m, int m_r) {
 // ---- LARGE systems (P = n + k beyond the register-distributed factorisation's 192, or an H that does not fit the LDS): H lives in a global
 // workspace of the workgroup (P x ldh, column-major, plan-owned, L2-resident: one per workgroup of the persistent grid), everything else stays
 // in LDS.  The J row chunk and the factorisation's column panel share one LDS region (they are never live together).
-__host__ __device__ inline int large_ld(int P) { return (P + 1) & ~1; }
+// (leading dimension of the global H: a multiple of 16 elements -- every column starts on a 128-byte line (fp64), so the 16-row strips the
+// factorisation and the solves read are whole lines; with the first version's even ld every other column straddled two: FETCH_SIZE 1.5 x)
+__host__ __device__ inline int large_ld(int P) { return (P + 15) & ~15; }
 #ifndef MO_LARGE_NB_MAX
 #define MO_LARGE_NB_MAX 32
 #endif
@@ -206,6 +219,13 @@ __device__ inline double absT(double v) { return fabs(v); }
 __device__ inline float absT(float v) { return fabsf(v); }
 __device__ inline double sqrtT(double v) { return sqrt(v); }
 __device__ inline float sqrtT(float v) { return sqrtf(v); }
+__device__ inline double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// A copy the optimiser cannot see through.  The LARGE kernel calls this on the thread index at the top of every phase: a predicate of
+// the lane index (lane == j, lane > jj, tid < wd ...) is loop-invariant, so LLVM computes each of the few hundred in the unrolled phases ONCE,
+// in front of the problem loop, and keeps all the masks live through the whole kernel -- 480 live SGPRs, 1 100 spills to VGPR lanes, and
+// the VGPRs holding those lanes spilled to scratch in turn.  From an opaque copy each mask is one v_cmp at its use.
+__device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 template <typename T> __device__ inline T nanT() { return (T)__builtin_nan(""); }
 template <typename T> __device__ inline bool finiteT(T v) { return __builtin_isfinite(v); }
 
@@ -328,23 +348,36 @@ __host__ __device__ inline int large_jtj_stride(int wc) { return wc + 16 + ((32 
 #ifndef MO_LARGE_TW
 #define MO_LARGE_TW 8   // 16 x 16 tiles of the trailing update a wave handles per round (its row strip x 16 MO_LARGE_TW columns)
 #endif
+#ifndef MO_LARGE_JPF
+#define MO_LARGE_JPF 2   // 4-row steps of J whose loads are issued together on the direct path (16 loads a lane at 2)
+#endif
+// G = J^T J (+ lambda on the diagonal) to the lower triangle of H, c = J^T r to cvec, |r|^2 to red[8], on the matrix cores over 128-wide
+// super-blocks.  Round 4: a PACKED or padded ROW-MAJOR J is read straight from global memory into the MFMA operands -- lane (l, g) of a
+// step takes row q + g, columns 16 e + l: every load instruction is four whole 128-byte segments -- with the loads of MO_LARGE_JPF steps
+// issued together; the LDS staging of the first version (a barrier and a round of latency per ~16-row chunk, three passes) is kept for the
+// column-major layout only.  Both paths feed the same steps in the same order (row q + g to lane group g), so every layout gives the same
+// bits.  c comes from the operands the diagonal blocks hold anyway (one FMA per loaded value, reduced over the four lane groups at the end).
 template <typename T>
-__device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r, int tid) {
+__device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, const T* J, int J_ld, int row_major, const T* r, T lambda, int tid) {
   typedef Mfma16<T> MF;
   typedef typename MF::Acc Acc;
   constexpr int TQ = MO_LARGE_TQ, SBW = 32 * TQ;   // a wave's quadrant is TQ x TQ tiles, the super-block 2 TQ x 2 TQ
+  constexpr int PF = MO_LARGE_JPF;
+  tid = opaque(tid);
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l = lane & 15;
   const int qa = (wave >> 1) & 1, qb = wave & 1;             // this wave's quadrant of the tiles: I tiles TQ qa .., J tiles TQ qb ..
+  if (wave == 1) {                                           // |r|^2: the wave without tiles on the first diagonal block
+    T racc = (T)0;
+#pragma unroll 4
+    for (int q = lane; q < m_r; q += 64) racc = fmaT(r[q], r[q], racc);
+    racc = wave_sum(racc);
+    if (lane == 0) w.red[8] = racc;
+  }
   for (int I0 = 0; I0 < n; I0 += SBW) {
     const int wi = n - I0 < SBW ? n - I0 : SBW;
     for (int J0 = 0; J0 <= I0; J0 += SBW) {
       const bool diag = J0 == I0;
       const int wj = diag ? 0 : SBW, wc = wi + wj;          // (J0 < I0: a full block of columns)
-      const int ws = large_jtj_stride(wc);
-      int CR = (w.region / (ws + 1)) & ~3;
-      if (CR < 4) return;                                  // (cannot happen: generic_large_lds_bytes refuses a region below four staged rows -- but never loop on a zero step)
-      if (CR > ((m_r + 3) & ~3)) CR = (m_r + 3) & ~3;
-      T* const rcs = w.Jc + (size_t)CR * ws;               // r of the staged rows
       // which of the wave's TQ x TQ tiles exist (wave-uniform): inside the block's columns, and on / below the diagonal of a diagonal block
       const int jw = diag ? wi : wj, joff = diag ? 0 : wi;
       bool need[TQ][TQ];
@@ -356,6 +389,8 @@ __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, cons
           need[a_][b_] = wave < 4 && 16 * (TQ * qa + a_) < wi && 16 * (TQ * qb + b_) < jw && (!diag || TQ * qb + b_ <= TQ * qa + a_);
           any = any || need[a_][b_];
         }
+      const bool do_c = diag && qb == 0 && wave < 4 && 16 * TQ * qa < wi;   // this wave also accumulates c for its I columns (wave-uniform)
+      const bool same = diag && qa == qb;                                   // the J operands are the I operands
       int ic[TQ], jc[TQ];                                    // clamped local columns: out-of-range operands are read (in bounds), their results never stored
 #pragma unroll
       for (int e = 0; e < TQ; ++e) {
@@ -364,64 +399,134 @@ __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, cons
         jc[e] = joff + (cj < jw ? cj : jw - 1);
       }
       Acc acc[TQ][TQ];
+      T cacc[TQ];
 #pragma unroll
-      for (int a_ = 0; a_ < TQ; ++a_)
+      for (int a_ = 0; a_ < TQ; ++a_) {
+        cacc[a_] = (T)0;
 #pragma unroll
         for (int b_ = 0; b_ < TQ; ++b_) acc[a_][b_] = Acc{(T)0, (T)0, (T)0, (T)0};
-      for (int q0 = 0; q0 < m_r; q0 += CR) {
-        const int rows = m_r - q0 < CR ? m_r - q0 : CR, rows4 = (rows + 3) & ~3;
-        // staging: every thread issues a batch of loads before it stores any of them (one round of global-memory latency per batch, not per
-        // element: the first version's element-by-element copy was most of the phase)
-        for (int base = 0; base < rows * wc; base += 8 * kThreads) {
-          T v[8];
-          int dst[8];
+      }
+      // tile rows of this wave with any needed tile (wave-uniform); the tiles of a row are computed together: all four, or the ones on / below
+      // the diagonal where the wave's quadrant sits on it (TRI, a compile-time flag: no per-tile branches in the loop).  Tiles beyond the
+      // block's columns are computed from clamped operands and never stored.
+      int na = 0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int idx = base + e * kThreads + tid;
-            dst[e] = -1;
-            v[e] = (T)0;
-            if (idx < rows * wc) {
-              int q, cx;
-              if (row_major) { q = idx / wc; cx = idx - q * wc; } else { cx = idx / rows; q = idx - cx * rows; }
-              const int col = cx < wi ? I0 + cx : J0 + cx - wi;
-              v[e] = row_major ? J[(size_t)(q0 + q) * J_ld + col] : J[(size_t)col * J_ld + q0 + q];
-              dst[e] = q * ws + cx;
+      for (int a_ = 0; a_ < TQ; ++a_) {
+        bool row_any = false;
+#pragma unroll
+        for (int b_ = 0; b_ < TQ; ++b_) row_any = row_any || need[a_][b_];
+        if (row_any) na = a_ + 1;
+      }
+      // one step: four rows of J (row q + g in lane group g)
+      auto step = [&](auto tri, const T (&bi)[TQ], const T (&aj)[TQ], T rv) {
+        constexpr bool TRI = decltype(tri)::value;
+#pragma unroll
+        for (int a_ = 0; a_ < TQ; ++a_) {
+          if (a_ >= na) continue;                            // (scalar)
+#pragma unroll
+          for (int b_ = 0; b_ < TQ; ++b_)
+            if (!TRI || b_ <= a_) acc[a_][b_] = MF::mac(aj[b_], bi[a_], acc[a_][b_]);
+        }
+        if (do_c) {
+#pragma unroll
+          for (int e = 0; e < TQ; ++e) cacc[e] = fmaT(bi[e], rv, cacc[e]);
+        }
+      };
+      auto run = [&](auto tri) {
+        constexpr bool TRI = decltype(tri)::value;           // (TRI <=> same: the J operands are the I operands)
+        if (row_major) {
+          if (any || do_c) {
+            int oi[TQ], oj[TQ];
+#pragma unroll
+            for (int e = 0; e < TQ; ++e) { oi[e] = I0 + ic[e]; oj[e] = (diag ? I0 : J0) + (jc[e] - joff); }
+            for (int q0 = 0; q0 < m_r; q0 += 4 * PF) {
+              T bi[PF][TQ], aj[PF][TQ], rv[PF];
+              const bool whole = q0 + 4 * PF <= m_r;         // (scalar)
+#pragma unroll
+              for (int s_ = 0; s_ < PF; ++s_) {
+                const int qq = q0 + 4 * s_ + g;
+                const int qc = (whole || qq < m_r) ? qq : m_r - 1;
+                const T* rowp = J + (size_t)qc * J_ld;
+#pragma unroll
+                for (int e = 0; e < TQ; ++e) bi[s_][e] = rowp[oi[e]];
+                if (!TRI) {
+#pragma unroll
+                  for (int e = 0; e < TQ; ++e) aj[s_][e] = rowp[oj[e]];
+                }
+                rv[s_] = do_c ? r[qc] : (T)0;
+              }
+              if (!whole) {                                  // the last rows: lanes beyond m_r contribute zeros
+#pragma unroll
+                for (int s_ = 0; s_ < PF; ++s_) {
+                  const bool ok = q0 + 4 * s_ + g < m_r;
+#pragma unroll
+                  for (int e = 0; e < TQ; ++e) { bi[s_][e] = ok ? bi[s_][e] : (T)0; if (!TRI) aj[s_][e] = ok ? aj[s_][e] : (T)0; }
+                }
+              }
+#pragma unroll
+              for (int s_ = 0; s_ < PF; ++s_) {
+                if (q0 + 4 * s_ >= m_r) continue;            // (scalar)
+                if (TRI) step(tri, bi[s_], bi[s_], rv[s_]);
+                else step(tri, bi[s_], aj[s_], rv[s_]);
+              }
             }
           }
+        } else {
+          const int ws = large_jtj_stride(wc);
+          int CR = (w.region / (ws + 1)) & ~3;
+          if (CR > ((m_r + 3) & ~3)) CR = (m_r + 3) & ~3;
+          if (CR < 4) return;                                // (cannot happen: generic_large_lds_bytes refuses a region below four staged rows -- but never loop on a zero step)
+          T* const rcs = w.Jc + (size_t)CR * ws;             // r of the staged rows
+          for (int q0 = 0; q0 < m_r; q0 += CR) {
+            const int rows = m_r - q0 < CR ? m_r - q0 : CR, rows4 = (rows + 3) & ~3;
+            // staging: every thread issues a batch of loads before it stores any of them (one round of global-memory latency per batch)
+            for (int base = 0; base < rows * wc; base += 8 * kThreads) {
+              T v[8];
+              int dst[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (dst[e] >= 0) w.Jc[dst[e]] = v[e];
-        }
-        for (int idx = tid; idx < (rows4 - rows) * wc; idx += kThreads) w.Jc[(size_t)(rows + idx / wc) * ws + idx % wc] = (T)0;
-        if (diag)
-          for (int idx = tid; idx < rows; idx += kThreads) rcs[idx] = r[q0 + idx];
-        __syncthreads();
-        if (any) {
-          for (int q = 0; q < rows4; q += 4) {
-            const T* row = w.Jc + (size_t)(q + g) * ws;
-            T bi[TQ], aj[TQ];
+              for (int e = 0; e < 8; ++e) {
+                const int idx = base + e * kThreads + tid;
+                dst[e] = -1;
+                v[e] = (T)0;
+                if (idx < rows * wc) {
+                  const int cx = idx / rows, q = idx - cx * rows;
+                  const int col = cx < wi ? I0 + cx : J0 + cx - wi;
+                  v[e] = J[(size_t)col * J_ld + q0 + q];
+                  dst[e] = q * ws + cx;
+                }
+              }
 #pragma unroll
-            for (int e = 0; e < TQ; ++e) { bi[e] = row[ic[e]]; aj[e] = row[jc[e]]; }
+              for (int e = 0; e < 8; ++e)
+                if (dst[e] >= 0) w.Jc[dst[e]] = v[e];
+            }
+            for (int idx = tid; idx < (rows4 - rows) * wc; idx += kThreads) w.Jc[(size_t)(rows + idx / wc) * ws + idx % wc] = (T)0;
+            if (diag)
+              for (int idx = tid; idx < rows4; idx += kThreads) rcs[idx] = idx < rows ? r[q0 + idx] : (T)0;
+            __syncthreads();
+            if (any || do_c) {
+              for (int q = 0; q < rows4; q += 4) {
+                const T* row = w.Jc + (size_t)(q + g) * ws;
+                T bi[TQ], aj[TQ];
 #pragma unroll
-            for (int a_ = 0; a_ < TQ; ++a_)
-#pragma unroll
-              for (int b_ = 0; b_ < TQ; ++b_)
-                if (need[a_][b_]) acc[a_][b_] = MF::mac(aj[b_], bi[a_], acc[a_][b_]);
+                for (int e = 0; e < TQ; ++e) { bi[e] = row[ic[e]]; aj[e] = row[jc[e]]; }
+                step(tri, bi, aj, do_c ? rcs[q + g] : (T)0);
+              }
+            }
+            __syncthreads();
           }
         }
-        if (diag) {                                          // c = J^T r for the columns of this diagonal block; 0.5 |r|^2 once
-          for (int i = tid; i < wi; i += kThreads) {
-            T cacc = 0;
-            for (int q = 0; q < rows; ++q) cacc += w.Jc[(size_t)q * ws + i] * rcs[q];
-            w.cvec[I0 + i] += cacc;
-          }
-          if (I0 == 0 && tid == 0) {
-            T racc = 0;
-            for (int q = 0; q < rows; ++q) racc += rcs[q] * rcs[q];
-            w.red[8] += racc;
-          }
+      };
+      if (same) run(std::true_type{});                       // (wave-uniform: every wave runs the same number of barriers either way)
+      else run(std::false_type{});
+      if (do_c) {                                            // c: the four lane groups' partial sums, in one fixed order
+#pragma unroll
+        for (int e = 0; e < TQ; ++e) {
+          T v = cacc[e];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          const int ci = 16 * (TQ * qa + e) + l;
+          if (g == 0 && ci < wi) w.cvec[I0 + ci] = v;
         }
-        __syncthreads();
       }
 #pragma unroll
       for (int a_ = 0; a_ < TQ; ++a_)
@@ -432,7 +537,11 @@ __device__ inline void accumulate_jtj_large(const Ws<T>& w, int n, int m_r, cons
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int j = J0 + 16 * (TQ * qb + b_) + MF::row(g, t);
-            if (i < n && j < n && j <= i) w.H[i + (size_t)j * w.ldh] = acc[a_][b_][t];
+            if (i < n && j < n && j <= i) {
+              T v = acc[a_][b_][t];
+              if (i == j && lambda > (T)0) v += lambda;      // (nonlinear.cc:182-189: the damping, in the same store)
+              w.H[i + (size_t)j * w.ldh] = v;
+            }
           }
         }
     }
@@ -447,13 +556,10 @@ __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T
   if (tid == 0) w.red[8] = (T)0;
   __syncthreads();
   if constexpr (LARGE) {
-    accumulate_jtj_large<T>(w, n, m_r, J, J_ld, row_major, r, tid);
-    __threadfence_block();   // the diagonal of G was stored by other threads than the ones that add lambda to it
+    accumulate_jtj_large<T>(w, n, m_r, J, J_ld, row_major, r, lambda, tid);
+    __threadfence_block();   // G is read by other threads than the ones that stored it
     __syncthreads();
-    if (lambda > (T)0)
-      for (int i = tid; i < n; i += kThreads) w.H[i + (size_t)i * w.ldh] += lambda;
     if (tid == 0) w.red[8] *= (T)0.5;
-    __threadfence_block();
     __syncthreads();
     return;
   }
@@ -495,8 +601,10 @@ __device__ MO_INLINE void accumulate_jtj(const Ws<T>& w, int n, int m_r, const T
 }
 
 // EvaluateKKTConditions, qp.cc:391-420.  H must hold G (lower) and A_eq (no Sigma yet).
-template <typename T>
+template <typename T> __device__ inline void eval_kkt_large(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid);
+template <bool LARGE = false, typename T>
 __device__ MO_INLINE void eval_kkt(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+  if constexpr (LARGE) { eval_kkt_large<T>(w, n, k, m, include_ineq, tid); return; }
   const T* x = w.vars; const T* s = w.vars + n; const T* y = w.vars + n + m; const T* z = w.vars + n + m + k;
   T* r_d = w.res; T* r_comp = w.res + n; T* r_pe = w.res + n + m; T* r_pi = w.res + n + m + k;
   for (int i = tid; i < n; i += kThreads) {
@@ -523,6 +631,98 @@ __device__ MO_INLINE void eval_kkt(const Ws<T>& w, int n, int k, int m, bool inc
     T acc = 0;
 #pragma unroll 8
     for (int j = 0; j < n; ++j) acc += w.H[n + q + (size_t)j * w.ldh] * x[j];
+    r_pe[q] = acc + w.beq[q];
+  }
+  if (include_ineq) {
+    for (int c = tid; c < m; c += kThreads) {                                     // :416-417
+      r_pi[c] = w.ca[c] * x[w.cv[c]] + w.cb[c] - s[c];
+      r_comp[c] = s[c] * z[c];
+    }
+  }
+  __syncthreads();
+}
+
+// LARGE (H in global memory): the same residuals from ONE coalesced pass over the lower triangle of [G; A_eq].  The loop above reads the
+// part of row i beyond the diagonal as column i -- a different 128-byte line per lane and load -- and gives r_pe to k threads with n
+// sequential loads each: 10 % of the n = 256 step.  Here a wave owns every fourth group of four columns, its lanes run down the rows (one
+// 512-byte segment per load), the loads of a group are issued together, and each element H[i][j] is used twice: times x[j] for row i's
+// sum (r_d below the diagonal, r_pe in the rows of A_eq), and times x[i] (or -y[i - n]) for column j's sum, which one wave reduction per
+// column finishes.  The sums run in a different (fixed) order than Eigen's; the rest of the function is the LDS version's.
+template <typename T>
+__device__ inline void eval_kkt_large(const Ws<T>& w, int n, int k, int m, bool include_ineq, int tid) {
+  constexpr int RT = 8, CB = 4;       // rows per lane of a pass (64 RT rows), columns whose loads are in flight together
+  const int P = n + k, ldh = w.ldh;
+  const T* x = w.vars; const T* s = w.vars + n; const T* y = w.vars + n + m; const T* z = w.vars + n + m + k;
+  T* r_d = w.res; T* r_comp = w.res + n; T* r_pe = w.res + n + m; T* r_pi = w.res + n + m + k;
+  tid = opaque(tid);
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = kThreads >> 6;
+  T* const rpart = w.Jc;                     // nw x P: the waves' partial row sums   (the panel region: nw P + n <= 8 (P | 1) elements)
+  T* const csum = rpart + (size_t)nw * P;    // n column sums; a column belongs to one wave
+  for (int i = tid; i < n; i += kThreads) csum[i] = (T)0;
+  __syncthreads();
+  for (int ib = 0; ib < P; ib += 64 * RT) {
+    T racc[RT], xx[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int i = ib + lane + 64 * t;
+      racc[t] = (T)0;
+      xx[t] = i < n ? x[i] : (i < P ? -y[i - n] : (T)0);
+    }
+    const int jmax = n < ib + 64 * RT ? n : ib + 64 * RT;    // columns with a row of this pass on or below the diagonal
+    for (int j0 = wave * CB; j0 < jmax; j0 += nw * CB) {
+      T v[CB][RT];
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int j = j0 + c;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          v[c][t] = (T)0;
+          if (j < jmax && ib + 64 * t + 63 >= j && ib + 64 * t < P) {   // (scalar)
+            const int i = ib + lane + 64 * t;
+            v[c][t] = w.H[(size_t)(i < P ? i : P - 1) + (size_t)j * ldh];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const int j = j0 + c;
+        if (j >= jmax) continue;                                         // (scalar)
+        const T xj = x[j];
+        T cp = (T)0;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          if (ib + 64 * t + 63 >= j && ib + 64 * t < P) {                 // (scalar)
+            const int i = ib + lane + 64 * t;
+            const T vv = (i >= j && i < P) ? v[c][t] : (T)0;             // (above the diagonal the workspace holds nothing)
+            racc[t] = fmaT(vv, xj, racc[t]);
+            cp = fmaT(i > j ? vv : (T)0, xx[t], cp);
+          }
+        }
+        cp = wave_sum(cp);
+        if (lane == 0) csum[j] += cp;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int i = ib + lane + 64 * t;
+      if (i < P) rpart[(size_t)wave * P + i] = racc[t];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kThreads) {
+    T rd = (T)0;
+    for (int wv = 0; wv < nw; ++wv) rd += rpart[(size_t)wv * P + i];
+    rd += csum[i];                                                      // (with -A_eq^T y, :406)
+    rd += w.cvec[i];
+    if (include_ineq) {
+      for (int c = 0; c < m; ++c)                                                 // :413-415, reference order per variable
+        if (w.cv[c] == i) rd -= w.ca[c] * z[c];
+    }
+    r_d[i] = rd;
+  }
+  for (int q = tid; q < k; q += kThreads) {                                       // :408
+    T acc = (T)0;
+    for (int wv = 0; wv < nw; ++wv) acc += rpart[(size_t)wv * P + n + q];
     r_pe[q] = acc + w.beq[q];
   }
   if (include_ineq) {
@@ -654,64 +854,70 @@ __device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
   return MO_STATUS_OK;
 }
 
-// One column panel of the blocked factorisation with the panel in REGISTERS: thread tid owns rows tid + 256 e (e < RPT) and keeps their wd <=
-// NBR values in registers.  Per pivot the owners of rows j .. wd - 1 publish column j's entries of the diagonal block (one of two alternating
-// LDS buffers at the start of the -- otherwise idle -- panel region), one barrier, and every thread updates its rows with broadcast reads:
-// a handful of instructions per pivot and row where the first version (panel in LDS, elements dealt out by a flat index) spent an integer
-// division, three LDS reads and an LDS write per ELEMENT.  Same arithmetic (one IEEE division per pivot, the same products in the same
-// order), same zero-pivot rules.  Leaves W = L D in H and in the LDS panel (for the trailing update), 1 / D in invd.  Returns the status.
-// FROM_LDS (the left-looking factorisation): the panel's current values -- H minus the update from every column in front of it -- were
-// staged in the LDS panel by left_update_panel; H itself is only WRITTEN here, once, with the finished W.
-template <typename T, int NBR, int RPT, bool FROM_LDS = false>
-__device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd, int rows, int ldp, int tid, bool& found_zero) {
-  T a[RPT][NBR];
+// One 16-column half panel of the blocked factorisation with the panel in REGISTERS: thread tid owns rows tid + 256 e (e < RPT) and keeps
+// their wd <= NBR values in registers; the panel's current values -- H minus the update from every column in front of it -- were staged in
+// the LDS panel by left_stage, and H itself is only WRITTEN here, once, with the finished W.
+// Round 4: NO barrier per pivot, and nothing but arithmetic in the pivot loop.  Every wave also keeps the 16 x 16 diagonal block in lanes
+// 0 .. 15 (t[]: lane = row) and factorises it redundantly; the pivot and the multipliers f = W[jj][j] / D[j] then come out of its own
+// registers by v_readlane -- scalars -- where the previous version published column j through LDS and waited for a workgroup barrier 16
+// times per half panel.  Same arithmetic (one IEEE division per pivot, the same products in the same order).  The zero-pivot rules are
+// NOT here: a zero (or NaN) pivot only raises a flag -- every wave sees the same pivots, so the flag needs no exchange -- and the function
+// then returns false having written nothing; the caller repeats the panel with the LDS loop that knows Eigen's rules (left_factor_half).
+// (The first cut had the rules in the loop: their branches cost a copy of the register panel at every join, then scratch reloads of spilled
+// SGPRs behind vmcnt(0) in every pivot -- 3 k cycles per pivot, more than the barriers it had replaced.)
+// Leaves W = L D in H and in the LDS panel (for the second half of the outer block), 1 / D in invd.
+template <typename T, int NBR, int RPT>
+__device__ inline bool factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd, int rows, int ldp, int tid) {
+  T a[RPT][NBR], t[NBR];
+  tid = opaque(tid);
+  const int lane = tid & 63;
+#ifdef MO_GENERIC_STAMPS
+  const unsigned long long fp_ta = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
   for (int e = 0; e < RPT; ++e) {
     const int i = tid + 256 * e;
 #pragma unroll
-    for (int jj = 0; jj < NBR; ++jj) {
-      if (FROM_LDS) a[e][jj] = (i < rows && jj < wd && i >= jj) ? panel[i + (size_t)jj * ldp] : (T)0;
-      else a[e][jj] = (i < rows && jj < wd && i >= jj) ? w.H[(size_t)(kb + i) + (size_t)(kb + jj) * w.ldh] : (T)0;
-    }
+    for (int jj = 0; jj < NBR; ++jj) a[e][jj] = (i < rows && jj < wd && i >= jj) ? panel[i + (size_t)jj * ldp] : (T)0;
   }
-  if (FROM_LDS) __syncthreads();   // the publish buffers below overlay the first elements of the staged panel
-  int status = MO_STATUS_OK;
-  int fz = uni((int)found_zero);   // scalar by construction: no decision of the pivot loop may become an EXEC-masked region around a[][]
+  // (a ragged last panel, wd < NBR: the missing columns are identity columns -- pivot 1, multipliers 0 -- so that the pivot loop has no
+  // condition on wd)
+#pragma unroll
+  for (int jj = 0; jj < NBR; ++jj) t[jj] = (lane < wd && jj <= lane) ? panel[lane + (size_t)jj * ldp] : ((lane == jj && lane < NBR) ? (T)1 : (T)0);
+  __syncthreads();   // every wave has its copy of the diagonal block before any wave overwrites the LDS panel with W
+#ifdef MO_GENERIC_STAMPS
+  const unsigned long long fp_t0 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) atomicAdd(&g_nd_stamps[9], fp_t0 - fp_ta);
+#endif
+  bool bad = false;  // (scalar: d is)
+  T invs = (T)0;
 #pragma unroll
   for (int j = 0; j < NBR; ++j) {
-    if (j >= wd || status != MO_STATUS_OK) continue;                              // (uniform)
-    T* const buf = panel + (j & 1) * (NBR + 1);
-    if (tid >= j && tid < wd) buf[tid] = a[0][j];
-    __syncthreads();
-    const T d = uni(buf[j]);                                                      // the pivot, as a scalar
-    if (!(absT(d) > (T)0)) {                                                      // zero (or NaN) pivot: Eigen's rules, as in factor_in_registers
-      bool nz = false;
-#pragma unroll
-      for (int e = 0; e < RPT; ++e) {
-        const int i = tid + 256 * e;
-        nz |= (i > j && i < rows && !(a[e][j] == (T)0));
-      }
-      if (nz || !(d == (T)0)) w.iflag[1] = 1;
-      if (tid == 0) w.invd[kb + j] = (T)0;
-      __syncthreads();
-      if (uni(w.iflag[1])) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }
-      fz = 1;
-      continue;
-    }
-    if (fz) { status = MO_STATUS_FACTORIZATION_FAILED; continue; }                // non-zero pivot after a zero pivot
+    const T d = rl(t[j], j);                                                      // the pivot, as a scalar
+    bad = bad || !(absT(d) > (T)0);
     const T inv = (T)1 / d;
-    if (tid == 0) w.invd[kb + j] = inv;
+    invs = lane == j ? inv : invs;                                                // lane j keeps 1 / D[j]: one masked store behind the loop
+    const T tj = t[j];
 #pragma unroll
     for (int jj = j + 1; jj < NBR; ++jj) {
-      if (jj >= wd) continue;
-      const T f = buf[jj] * inv;
+      const T f = rl(tj, jj) * inv;
+      t[jj] -= tj * f;
 #pragma unroll
-      for (int e = 0; e < RPT; ++e) a[e][jj] -= a[e][j] * f;                       // (entries above the diagonal are never read)
+      for (int e = 0; e < RPT; ++e) {
+        a[e][jj] -= a[e][j] * f;                                                   // (entries above the diagonal are never read)
+        asm volatile("" : "+v"(a[e][jj]));   // (pinned: LLVM otherwise sinks the panel's updates behind the `bad` exit and keeps all 120
+                                             // multipliers for them -- in scratch)
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);   // (one scheduling region per pivot: across all 16 the scheduler's order spills the panel)
   }
-  __syncthreads();                                                                // the publish buffers live in the panel region
-  found_zero = fz != 0;
-  if (status != MO_STATUS_OK) return status;
+#ifdef MO_GENERIC_STAMPS
+  const unsigned long long fp_t1 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) atomicAdd(&g_nd_stamps[7], fp_t1 - fp_t0);
+  if (tid == 0 && uni((int)bad)) atomicAdd(&g_nd_stamps[8], 1ull);
+#endif
+  if (uni((int)bad)) return false;
+  if (tid < wd) w.invd[kb + tid] = invs;
 #pragma unroll
   for (int e = 0; e < RPT; ++e) {
     const int i = tid + 256 * e;
@@ -724,7 +930,10 @@ __device__ inline int factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd
       }
     }
   }
-  return status;
+#ifdef MO_GENERIC_STAMPS
+  if (tid == 0) atomicAdd(&g_nd_stamps[10], __builtin_amdgcn_s_memtime() - fp_t1);
+#endif
+  return true;
 }
 // LARGE: LEFT-LOOKING blocked LDL^T with H in global memory (round 4; same natural order, same zero-pivot rules, same result layout: W = L D
 // below the diagonal, invd = 1 / D).  Round 3 was right-looking -- after every 16-column panel the whole trailing matrix was read, updated and
@@ -761,8 +970,46 @@ __device__ inline void left_accumulate(const Ws<T>& w, const T* src, int ld, int
     const int j = 16 * (c_first + c) + l;
     jrow[c] = colrow_base + (j < rows_avail ? j : rows_avail - 1);
   }
-#pragma unroll 2
-  for (int q = c_begin; q < c_end; q += 4) {
+  // Software pipeline (round 4): the columns come from global memory (HBM / MALL latency: the per-workgroup H does not stay in L2) and the
+  // first version waited for every 4-column step's loads before its MFMAs.  Now the loads of 16 columns (4 steps: 28 loads a lane) are
+  // issued together and the scale by 1 / D happens at consumption, not at the load: one round of latency per 40 MFMAs, which the other
+  // workgroup's waves on the SIMD fill.  (Two batches in flight, ping-pong, cost 128 registers beside the 80 accumulators: 1 KB of spills.)
+  constexpr int PF = 4;
+  struct Batch { T aj[PF][C16], bi[PF][kLeftSPW], inv[PF]; };
+  auto load = [&](int q0, Batch& b) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int col = q0 + 4 * s + g;
+      const T* colp = src + (size_t)col * ld;
+      b.inv[s] = w.invd[inv_base + col];
+#pragma unroll
+      for (int c = 0; c < C16; ++c) b.aj[s][c] = colp[jrow[c]];
+#pragma unroll
+      for (int sl = 0; sl < kLeftSPW; ++sl) b.bi[s][sl] = have[sl] ? colp[irow[sl]] : (T)0;
+    }
+  };
+  auto consume = [&](const Batch& b) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      T a[C16];
+#pragma unroll
+      for (int c = 0; c < C16; ++c) a[c] = b.aj[s][c] * b.inv[s];
+#pragma unroll
+      for (int sl = 0; sl < kLeftSPW; ++sl) {
+        if (!have[sl]) continue;
+#pragma unroll
+        for (int c = 0; c < C16; ++c) acc[sl][c] = MF::mac(a[c], b.bi[s][sl], acc[sl][c]);
+      }
+    }
+  };
+  const int nfull = (c_end - c_begin) / (4 * PF);
+  int q = c_begin;
+  for (int it = 0; it < nfull; ++it, q += 4 * PF) {
+    Batch b;
+    load(q, b);
+    consume(b);
+  }
+  for (; q < c_end; q += 4) {   // (a ragged tail only where the blocks are 8 columns wide: very large systems)
     const bool valid = q + g < c_end;
     const int col = valid ? q + g : c_begin;
     const T inv = valid ? w.invd[inv_base + col] : (T)0;
@@ -781,8 +1028,31 @@ __device__ inline void left_accumulate(const Ws<T>& w, const T* src, int ld, int
   }
   (void)FROM_PANEL;
 }
-// Stage H[kb + i][kb + 16 c + j] - acc for the rows of this chunk and tile column c into the LDS panel of the half that starts at panel column
-// 16 c (rows relative to that half: i - 16 c), zeros above the diagonal.
+// acc = -H[kb + i][kb + 16 c + j] for the rows of this chunk: the block's own values enter the accumulators BEFORE the update products are
+// added (their loads are in flight during left_accumulate instead of being waited for between the accumulation and the staging).
+template <typename T, int C16>
+__device__ inline void left_init(const Ws<T>& w, int kb, int rows, int wd, int r0, int lane, int wave, typename Mfma16<T>::Acc (&acc)[kLeftSPW][C16]) {
+  typedef Mfma16<T> MF;
+  const int g = lane >> 4, l = lane & 15;
+#pragma unroll
+  for (int sl = 0; sl < kLeftSPW; ++sl) {
+    const int i = r0 + 16 * (4 * sl + wave) + l;                // panel row
+    const bool strip = r0 + 16 * (4 * sl + wave) < rows;        // wave-uniform
+    const int ic = i < rows ? i : rows - 1;
+#pragma unroll
+    for (int c = 0; c < C16; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = 16 * c + MF::row(g, t);                   // panel column
+        const int jc = j < wd ? j : wd - 1;
+        T v = (T)0;
+        if (strip) v = w.H[(size_t)(kb + ic) + (size_t)(kb + jc) * w.ldh];   // (clamped: in bounds; a scalar branch around the loads)
+        acc[sl][c][t] = (i < rows && j < wd && j <= i) ? -v : (T)0;
+      }
+  }
+}
+// Stage -acc = H[kb + i][kb + 16 c + j] - (update) for the rows of this chunk and tile column c into the LDS panel of the half that starts at
+// panel column 16 c (rows relative to that half: i - 16 c), zeros above the diagonal.
 template <typename T, int C16>
 __device__ inline void left_stage(const Ws<T>& w, T* panel, int kb, int rows, int wd, int c, int r0, int lane, int wave,
                                   const typename Mfma16<T>::Acc (&acc)[kLeftSPW][C16]) {
@@ -797,7 +1067,7 @@ __device__ inline void left_stage(const Ws<T>& w, T* panel, int kb, int rows, in
     for (int t = 0; t < 4; ++t) {
       const int j = 16 * c + MF::row(g, t);                     // panel column
       if (i < rows && i >= 16 * c && j < wd) {
-        const T v = j <= i ? w.H[(size_t)(kb + i) + (size_t)(kb + j) * w.ldh] - acc[sl][c][t] : (T)0;
+        const T v = j <= i ? -acc[sl][c][t] : (T)0;
         panel[(i - 16 * c) + (size_t)(j - 16 * c) * ldp] = v;
       }
     }
@@ -808,11 +1078,14 @@ template <typename T>
 __device__ inline int left_factor_half(const Ws<T>& w, T* panel, int kb, int wd, int rows, int tid, bool& found_zero) {
   const int ldp = rows | 1;
   int status = MO_STATUS_OK;
-  if (uni((int)kThreads) == 256 && rows <= 512) {
-    if (rows <= 256) status = factor_panel_regs<T, 16, 1, true>(w, panel, kb, wd, rows, ldp, tid, found_zero);
-    else status = factor_panel_regs<T, 16, 2, true>(w, panel, kb, wd, rows, ldp, tid, found_zero);
+  tid = opaque(tid);
+  if (uni((int)kThreads) == 256 && rows <= 512 && !uni((int)found_zero)) {
+    bool done;
+    if (rows <= 256) done = factor_panel_regs<T, 16, 1>(w, panel, kb, wd, rows, ldp, tid);
+    else done = factor_panel_regs<T, 16, 2>(w, panel, kb, wd, rows, ldp, tid);
     __syncthreads();                                                             // the LDS copy of W is read by other threads
-    return status;
+    if (done) return status;
+    // (a zero or NaN pivot in this half panel: nothing was written; the loop below applies the rules)
   }
   for (int j = 0; j < wd; ++j) {                                                 // any size: the panel stays in LDS
     const T d = uni(panel[j + (size_t)j * ldp]);                                  // the pivot, as a scalar
@@ -855,20 +1128,28 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
   int status = MO_STATUS_OK;
   // (the LARGE kernel is launched with exactly four waves: launch_generic_large.  The wave index is made scalar so that the per-strip
   // conditions below are scalar branches, not EXEC-masked regions around the accumulator tiles.)
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int kb = 0;
+#ifdef MO_GENERIC_STAMPS
+  unsigned long long fb_prev = __builtin_amdgcn_s_memtime();
+#endif
   while (kb < P && status == MO_STATUS_OK) {
     const int rows = P - kb;
+    tid = opaque(tid);
+    const int lane = tid & 63;
     if (rows <= 64 * kLeftSPW) {
       // ---- a 32-column outer block in one chunk of rows: both halves' accumulators live in registers
       const int wd = rows < 32 ? rows : 32;
       Acc acc[kLeftSPW][2];
-#pragma unroll
-      for (int sl = 0; sl < kLeftSPW; ++sl) { acc[sl][0] = Acc{(T)0, (T)0, (T)0, (T)0}; acc[sl][1] = Acc{(T)0, (T)0, (T)0, (T)0}; }
+      left_init<T, 2>(w, kb, rows, wd, 0, lane, wave, acc);
+      MO_FBSTAMP(2);
       left_accumulate<T, 2, false>(w, w.H, w.ldh, kb, kb, 0, kb, 0, rows, 0, 0, lane, wave, acc);
+      MO_FBSTAMP(3);
       left_stage<T, 2>(w, panel, kb, rows, wd, 0, 0, lane, wave, acc);
       __syncthreads();
+      MO_FBSTAMP(4);
       status = uni(left_factor_half<T>(w, panel, kb, wd < 16 ? wd : 16, rows, tid, found_zero));
+      MO_FBSTAMP(5);
       if (status != MO_STATUS_OK) break;
       if (wd > 16) {
         // second half: the columns of the first half come from its LDS copy (rows relative to the first half's panel)
@@ -882,9 +1163,12 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
           for (int sl = 0; sl < kLeftSPW; ++sl) acc[sl][1] = one[sl][0];
         }
         __syncthreads();                                                            // every wave is done with the first half's LDS copy
+        MO_FBSTAMP(6);
         left_stage<T, 2>(w, panel, kb, rows, wd, 1, 0, lane, wave, acc);
         __syncthreads();
+        MO_FBSTAMP(4);
         status = uni(left_factor_half<T>(w, panel, kb + 16, wd - 16, rows - 16, tid, found_zero));
+        MO_FBSTAMP(5);
       }
       kb += wd;
     } else {
@@ -892,8 +1176,7 @@ __device__ MO_INLINE int factor_blocked(const Ws<T>& w, int P, int NB, int tid) 
       const int wd = NB < 16 ? NB : 16;
       for (int r0 = 0; r0 < rows; r0 += 64 * kLeftSPW) {
         Acc acc[kLeftSPW][1];
-#pragma unroll
-        for (int sl = 0; sl < kLeftSPW; ++sl) acc[sl][0] = Acc{(T)0, (T)0, (T)0, (T)0};
+        left_init<T, 1>(w, kb, rows, wd, r0, lane, wave, acc);
         left_accumulate<T, 1, false>(w, w.H, w.ldh, kb, kb, 0, kb, 0, rows, r0, 0, lane, wave, acc);
         left_stage<T, 1>(w, panel, kb, rows, wd, 0, r0, lane, wave, acc);
       }
@@ -919,9 +1202,59 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
   const int ldb = SB + 1;
   T* const dblk = w.Jc;                 // the triangle, column-major, ld = SB + 1
   T* const tvec = dblk + SB * ldb;      // SB scaled unknowns / SB partial dot products
-  const int lane = tid & 63, wave = tid >> 6, nwaves = kThreads >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = kThreads >> 6;
   for (int c0 = 0; c0 < P; c0 += SB) {
     const int wd = P - c0 < SB ? P - c0 : SB;
+    tid = opaque(tid);
+    const int lane = tid & 63;
+    if (wd == 32) {
+      // A whole 32-column block (round 4): nothing staged, nothing waited for twice.  Every thread first ISSUES the 32 loads of its row
+      // below the block; wave 0 takes its rows of the triangle straight from global memory (lane = row: coalesced), solves them with the
+      // unknowns in registers and compile-time lane indices, and publishes the scaled unknowns; after ONE barrier the rows below -- their
+      // operands long since arrived -- take their 32-term update.  Same products, same order as the staged version below.
+      const int i0 = c0 + 32 + tid;
+      T hv[32];
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) hv[jj] = (T)0;
+      if (i0 < P) {
+        const T* row = w.H + (size_t)i0 + (size_t)c0 * w.ldh;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) hv[jj] = row[(size_t)jj * w.ldh];
+      }
+      if (wave == 0) {
+        const int lr = lane < 32 ? lane : 31;
+        const T* trow = w.H + (size_t)(c0 + lr) + (size_t)c0 * w.ldh;
+        T tri[32];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) tri[jj] = trow[(size_t)jj * w.ldh];     // (on and above the diagonal: read, never used)
+        const T invl = w.invd[c0 + lr];
+        T zi = w.rhs[c0 + lr];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+          const T tj = rl(zi, jj) * rl(invl, jj);
+          if (lane > jj && lane < 32) zi -= tri[jj] * tj;
+        }
+        if (lane < 32) { w.rhs[c0 + lane] = zi; tvec[lane] = zi * invl; }
+      }
+      __syncthreads();
+      if (i0 < P) {
+        T acc = (T)0;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) acc += hv[jj] * tvec[jj];
+        w.rhs[i0] -= acc;
+      }
+      for (int i = i0 + kThreads; i < P; i += kThreads) {       // (more than 256 rows below the block)
+        const T* row = w.H + (size_t)i + (size_t)c0 * w.ldh;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) hv[jj] = row[(size_t)jj * w.ldh];
+        T acc = (T)0;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) acc += hv[jj] * tvec[jj];
+        w.rhs[i] -= acc;
+      }
+      __syncthreads();
+      continue;
+    }
 #pragma unroll 4
     for (int idx = tid; idx < wd * wd; idx += kThreads) {
       const int jj = idx / wd, i = idx - jj * wd;
@@ -940,8 +1273,16 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
     for (int i = c0 + wd + tid; i < P; i += kThreads) {
       const T* row = w.H + (size_t)i + (size_t)c0 * w.ldh;
       T acc = (T)0;
+      if (wd == 32) {                 // a whole block: its 32 loads are in flight together (one round of latency, not four)
+        T hv[32];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) hv[jj] = row[(size_t)jj * w.ldh];
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) acc += hv[jj] * tvec[jj];
+      } else {
 #pragma unroll 8
-      for (int jj = 0; jj < wd; ++jj) acc += row[(size_t)jj * w.ldh] * tvec[jj];
+        for (int jj = 0; jj < wd; ++jj) acc += row[(size_t)jj * w.ldh] * tvec[jj];
+      }
       w.rhs[i] -= acc;
     }
     __syncthreads();
@@ -949,21 +1290,72 @@ __device__ MO_INLINE void block_solve(const Ws<T>& w, int P, int region, int tid
   const int last = ((P - 1) / SB) * SB;
   for (int c0 = last; c0 >= 0; c0 -= SB) {
     const int wd = P - c0 < SB ? P - c0 : SB, below = c0 + wd;
+    const bool whole = wd == 32;
+    tid = opaque(tid);
+    const int lane = tid & 63;
+    T colv[32];                                  // whole block: lane = column of the triangle, its entries below the diagonal in registers
+    if (whole) {
+      if (wave == 0) {
+        const int lc = lane < 32 ? lane : 31;
+        const T* cp = w.H + (size_t)c0 + (size_t)(c0 + lc) * w.ldh;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) colv[i] = cp[i];                            // (on and above the diagonal: read, never used)
+      }
+    } else {
 #pragma unroll 4
-    for (int idx = tid; idx < wd * wd; idx += kThreads) {
-      const int jj = idx / wd, i = idx - jj * wd;
-      dblk[i + jj * ldb] = i > jj ? w.H[(size_t)(c0 + i) + (size_t)(c0 + jj) * w.ldh] : (T)0;
+      for (int idx = tid; idx < wd * wd; idx += kThreads) {
+        const int jj = idx / wd, i = idx - jj * wd;
+        dblk[i + jj * ldb] = i > jj ? w.H[(size_t)(c0 + i) + (size_t)(c0 + jj) * w.ldh] : (T)0;
+      }
     }
-    for (int jj = wave; jj < wd; jj += nwaves) {
-      const T* col = w.H + (size_t)(c0 + jj) * w.ldh;
-      T sacc = (T)0;
-#pragma unroll 4
-      for (int i = below + lane; i < P; i += 64) sacc += col[i] * w.rhs[i];
-      sacc = wave_sum(sacc);
-      if (lane == 0) tvec[jj] = sacc;
+    // the dot products with the solution below the block: a wave takes every nwaves-th column, four of its columns at a time with the
+    // loads of four 64-row chunks each in flight together (16 a lane; one column at a time was a round of latency per column).  Per
+    // column the sum runs over the chunks in order, as before.
+    for (int jb = wave; jb < wd; jb += 4 * nwaves) {
+      T sacc[4] = {(T)0, (T)0, (T)0, (T)0};
+      for (int ib = below; ib < P; ib += 4 * 64) {
+        T hv[4][4], xv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = ib + lane + 64 * t;
+          xv[t] = i < P ? w.rhs[i] : (T)0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int jj = jb + c * nwaves;
+            hv[c][t] = (T)0;
+            if (jj < wd && ib + 64 * t < P)                       // (scalar)
+              hv[c][t] = w.H[(size_t)(i < P ? i : P - 1) + (size_t)(c0 + jj) * w.ldh];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (ib + 64 * t < P) sacc[c] += (ib + lane + 64 * t < P ? hv[c][t] : (T)0) * xv[t];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int jj = jb + c * nwaves;
+        if (jj >= wd) continue;                                   // (scalar)
+        const T tot = wave_sum(sacc[c]);
+        if (lane == 0) tvec[jj] = tot;
+      }
     }
     __syncthreads();
-    if (tid < 64) {
+    if (whole) {
+      if (wave == 0) {                           // the transposed triangle on wave 0, compile-time lane indices
+        const int lc = lane < 32 ? lane : 31;
+        const T invl = w.invd[c0 + lc];
+        T v = w.rhs[c0 + lc] - tvec[lc], mine = (T)0;
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+          const T xi = rl(v, i) * rl(invl, i);
+          if (lane == i) mine = xi;
+          if (lane < i) v -= colv[i] * xi;
+        }
+        if (lane < 32) w.rhs[c0 + lane] = mine;
+      }
+    } else if (tid < 64) {
       T v = lane < wd ? w.rhs[c0 + lane] - tvec[lane] : (T)0, mine = (T)0;
       for (int i = wd - 1; i >= 0; --i) {
         const T xi = rl(v, i) * w.invd[c0 + i];
@@ -1170,8 +1562,7 @@ template <typename T, int MODE, int TG, int R, bool LARGE = false>
 __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ws<T> w;
-  const int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
-  const int V = n + 2 * m + k;
+  int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
   if constexpr (LARGE) carve_large(w, smem, (T*)a.H_work + (size_t)blockIdx.x * (size_t)a.H_work_stride, n, k, m, m_r);
   else carve(w, smem, n, k, m, m_r);
   const int tid = threadIdx.x;
@@ -1183,6 +1574,14 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
   for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
     if (MODE == MODE_SOLVE && a.skip && a.skip[p * a.skip_stride] >= 0) continue;  // uniform: finished in the caller's outer loop
     __syncthreads();  // previous problem's readers are done with LDS
+    if constexpr (LARGE) {
+      // The sizes are the same for every problem, and LLVM knows it: it hoisted every scalar that depends only on them -- the tile masks of
+      // each J^T J block, panel widths, loop bounds, hundreds of them -- out of this loop, where they stayed live across all phases: 1 100
+      // SGPR spills to VGPR lanes, and the VGPRs holding those lanes spilled to scratch in turn (each reload a vmcnt(0) wait behind the other
+      // workgroup's memory traffic).  Opaque copies per problem: the scalars are recomputed where they are used.
+      asm volatile("" : "+s"(n), "+s"(k), "+s"(m), "+s"(m_r));
+    }
+    const int V = n + 2 * m + k;
     const T* Jp = j_level ? (const T*)a.J + p * a.J_stride : nullptr;
     const T* rp = j_level ? (const T*)a.r + p * a.r_stride : nullptr;
     const T* Gp = a.G ? (const T*)a.G + p * a.G_stride : nullptr;
@@ -1245,7 +1644,7 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
 
     if (MODE == MODE_RESIDUAL) {
       const bool inc = !(a.flags & MO_STEP_NO_INEQUALITIES);
-      eval_kkt(w, n, k, m, inc, tid);
+      eval_kkt<LARGE>(w, n, k, m, inc, tid);
       compute_errors(w, n, k, m, mu_p, tid);
       T* ro = (T*)a.r_out + p * a.r_out_stride;
       for (int i = tid; i < V; i += kThreads) ro[i] = w.res[i];
@@ -1259,7 +1658,7 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
       const bool no_ineq = (a.flags & MO_STEP_NO_INEQUALITIES) != 0;
       for (int i = tid; i < V; i += kThreads) { w.delta[i] = (T)0; w.daff[i] = (T)0; }
       if (st == MO_STATUS_OK) {
-        eval_kkt(w, n, k, m, !no_ineq, tid);
+        eval_kkt<LARGE>(w, n, k, m, !no_ineq, tid);
         MO_GSTAMP(3);
         if (no_ineq) {
           st = assemble_and_factor<T, TG, R, LARGE>(w, n, k, m, false, tid, m_r);
@@ -1315,7 +1714,7 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
         for (int q = tid; q < k; q += kThreads) y[q] = (T)0;
         __syncthreads();
         if (sp.initial_guess_method == MO_GUESS_SOLVE_EQUALITY_CONSTRAINED) {     // :455-460
-          eval_kkt(w, n, k, m, false, tid);
+          eval_kkt<LARGE>(w, n, k, m, false, tid);
           st = assemble_and_factor<T, TG, R, LARGE>(w, n, k, m, false, tid, m_r);
           if (st == MO_STATUS_OK) {
             solve_for_update<T, LARGE>(w, n, k, m, (T)0, false, tid);
@@ -1346,7 +1745,7 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
       }
       T mu = (T)sp.initial_mu;
       if (st == MO_STATUS_OK) {
-        eval_kkt(w, n, k, m, true, tid);                                          // :110
+        eval_kkt<LARGE>(w, n, k, m, true, tid);                                          // :110
         if (sp.initialize_mu_with_complementarity) { compute_mu(w, n, k, m, tid); mu = w.red[4]; }  // :115
       }
       T* iter_out = a.iterations ? (T*)a.iterations + (size_t)p * sp.max_iterations * MO_ITER_RECORD : nullptr;
@@ -1360,7 +1759,7 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
         if (st != MO_STATUS_OK) break;
         update_state(w, n, k, m, rec[9], rec[10], tid);
         load_qp(w, n, k, Gp, G_ld, cp, Ap, a.A_ld, bp, tid);
-        eval_kkt(w, n, k, m, true, tid);                                          // :125
+        eval_kkt<LARGE>(w, n, k, m, true, tid);                                          // :125
         compute_errors(w, n, k, m, mu, tid);                                      // :127
         rec[4] = w.red[0]; rec[5] = w.red[1]; rec[6] = w.red[2]; rec[7] = w.red[3];
         __syncthreads();
@@ -1714,7 +2113,12 @@ static hipError_t launch_generic_large(const KernelArgs& a, int dtype, int num_c
     case MODE_SOLVE: MO_LAUNCH_LARGE(TYPE, MODE_SOLVE); break;         \
     default: return hipErrorInvalidValue;                             \
   }
+#ifdef MO_GENERIC_LARGE_STEP_ONLY   // development builds: the fp64 step kernel alone (register-pressure probes)
+  if (dtype != MO_F64 || a.mode != MODE_STEP) return hipErrorInvalidValue;
+  MO_LAUNCH_LARGE(double, MODE_STEP);
+#else
   if (dtype == MO_F64) { MO_DISPATCH_LARGE(double) } else { MO_DISPATCH_LARGE(float) }
+#endif
 #undef MO_DISPATCH_LARGE
 #undef MO_LAUNCH_LARGE
   return hipGetLastError();

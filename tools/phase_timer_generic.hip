@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
     const size_t wgs = (size_t)mo::generic_large_grid(a, 8, prop.multiProcessorCount);
     CK(hipMalloc(&a.H_work, wgs * per_wg * 8));
     a.H_work_stride = (long long)per_wg;
+    a.H_work_slots = (int)wgs;
     printf("LARGE path: %zu workgroups, %zu B of H each, %zu B of LDS\n", wgs, per_wg * 8, mo::generic_large_lds_bytes(a, 8));
   }
 
@@ -83,9 +84,13 @@ int main(int argc, char** argv) {
            h[11] / (double)h[8] / 100.0, h[12] / 100.0, (tot / h[8]) / (h[11] / (double)h[8] / 100.0) / 1e3);
     printf("  total %.0f ticks per problem per wave (s_memtime ticks: 100 MHz constant clock => x ~21 for core cycles)\n", tot / batch);
   }
-  unsigned long long nd[8];
+  unsigned long long nd[16];
   CK(hipMemcpyFromSymbol(nd, HIP_SYMBOL(mo::g_nd_stamps), sizeof(nd)));
   printf("  inside newton_direction (3 launches summed): assemble + factorise %llu, rhs + solve + ds/dz %llu ticks per problem\n",
          nd[0] / (3 * batch), nd[1] / (3 * batch));
+  printf("  inside factor_blocked: other (assembly, loop) %llu, accumulate from H %llu, stage %llu, factor half %llu, accumulate from panel %llu ticks per problem; pivot loops alone (wave 0) %llu\n",
+         nd[2] / (3 * batch), nd[3] / (3 * batch), nd[4] / (3 * batch), nd[5] / (3 * batch), nd[6] / (3 * batch), nd[7] / (3 * batch));
+  printf("  factor_panel_regs (wave 0): LDS loads + barrier %llu, stores issued %llu ticks per problem; fallbacks to the LDS loop: %llu in %llu problems\n",
+         nd[9] / (3 * batch), nd[10] / (3 * batch), nd[8], (unsigned long long)(3 * batch));
   return 0;
 }
