@@ -114,6 +114,12 @@ __device__ inline void lds_fence32() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "
 #ifndef MO_F32_LOOKAHEAD
 #define MO_F32_LOOKAHEAD 0   // A/B knob: 1 = look-ahead elimination (measured: -2.2 % at BASELINE configs[3])
 #endif
+#ifndef MO_F32_RHS_VECTOR   // A/B knob (step kernel): 0 = the right-hand side in tile column NT + 1, as in rounds 1 - 3
+#define MO_F32_RHS_VECTOR (!MO_F32_LOOKAHEAD)   // round 4: a vector (registers + two LDS hops per block step): -180 MFMAs at NT = 8, +1.0 %
+#endif
+#if MO_F32_RHS_VECTOR && MO_F32_LOOKAHEAD
+#error "the look-ahead elimination schedules the MFMAs of tile column NT + 1: build it with -DMO_F32_RHS_VECTOR=0"
+#endif
 template <unsigned long long MASK> __device__ inline void masked_set_f32(float& dst, float src) {
   unsigned long long save;
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\tv_mov_b32 %[d], %[s]\n\t"
@@ -578,13 +584,28 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
           const int natcol = 64 * (c >> 2) + 16 * g + 4 * t + (c & 3);  // variable at position 16c + 4g + t
           U[c * NB + c][t] += (j == 4 * g + t) ? ((!PAD || natcol < nn) ? lam + dS[c] : 1.0f) : 0.0f;   // padding: identity rows, zero right-hand side
           U[c * NB + NT][t] = (j < k && (!PAD || natcol < nn)) ? Ap[j + (size_t)natcol * A_ld] : 0.0f;
+#if !MO_F32_RHS_VECTOR
           const float rv = rp[16 * c + 4 * g + t];
           U[c * NB + NR][t] = (j == 0) ? rv : 0.0f;
+#endif
         }
       }
+#if !MO_F32_RHS_VECTOR
 #pragma unroll
       for (int t = 0; t < 4; ++t) U[NT * NB + NR][t] = (j == 0 && 4 * g + t < k) ? -bb[4 * g + t] : 0.0f;  // -b_eq
+#endif
     }
+#if MO_F32_RHS_VECTOR
+    // The right-hand side as a VECTOR: rj[c] = its entry at position 16 c + j (every lane group holds a copy).  Tile column NT + 1 costs
+    // 4 MFMAs per tile product for one useful column in sixteen (180 MFMAs at NT = 8); the vector pays 4 FMAs + a cross-row sum per product
+    // and two LDS hops per block step (lane j <-> rows 4 g .. 4 g + 3, the layout a tile product wants its operand in).  rp (= diagS) holds
+    // the blocks 0 .. NT - 1 the back-substitution reads; block NT and the hop buffer zS follow it in rhsS (dead until dxs is written).
+    float rj[NT + 1];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) rj[c] = rS[c] - cvec[c];
+    rj[NT] = (j < k) ? -bb[j] : 0.0f;                                 // -b_eq
+    float* const zS = rhsS + 16;
+#endif
 
     // ---- P5: block elimination with 16x16 pivot blocks (pivot blocks 0..NT; column NR only rides along)
     __builtin_amdgcn_sched_barrier(0);
@@ -595,16 +616,45 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
 #else
 #pragma unroll
     for (int pa = 0; pa <= NT; ++pa) {
+#if MO_F32_RHS_VECTOR
+      if (g == 0) rp[16 * pa + j] = rj[pa];                           // block pa of the right-hand side is final: to LDS (the sweep covers the hop)
+#endif
       ok = sweep_tile_f32(U[pa * NB + pa], pa < NT ? 16 : k, j) && ok;
       __builtin_amdgcn_sched_barrier(0);
       MO_STAMP32(3);
+#if MO_F32_RHS_VECTOR
+      {
+        lds_fence32();
+        const f4 ra4 = *(const f4*)(rp + 16 * pa + 4 * g);            // rows 4 g .. 4 g + 3 of block pa
+        float zs = 0.0f;
 #pragma unroll
-      for (int pc = pa + 1; pc < NB; ++pc) {
+        for (int t = 0; t < 4; ++t) zs = fmaf(U[pa * NB + pa][t], ra4[t], zs);
+        zs = cross_row_sum_f32(zs);                                   // (-T^-1) r_a at position j
+        if (g == 0) zS[j] = zs;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int pc = pa + 1; pc < (MO_F32_RHS_VECTOR ? NB - 1 : NB); ++pc) {
         const f4 negZ = mfma4_f32(U[pa * NB + pa], U[pa * NB + pc], f4{0.0f, 0.0f, 0.0f, 0.0f});  // (-T^-1) U_ac
 #pragma unroll
         for (int pb = pa + 1; pb <= (pc < NT ? pc : NT); ++pb) U[pb * NB + pc] = mfma4_f32(U[pa * NB + pb], negZ, U[pb * NB + pc]);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if MO_F32_RHS_VECTOR
+      if (pa < NT) {
+        lds_fence32();
+        const f4 z4 = *(const f4*)(zS + 4 * g);
+#pragma unroll
+        for (int pb = pa + 1; pb <= NT; ++pb) {
+          float us = 0.0f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) us = fmaf(U[pa * NB + pb][t], z4[t], us);
+          rj[pb] += cross_row_sum_f32(us);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       MO_STAMP32(4);
     }
 #endif
@@ -622,7 +672,11 @@ __global__ __launch_bounds__(256 * WPS, WPS) void kkt_fused_f32_kernel(const Ker
 #pragma unroll
         for (int pb = pa + 1; pb <= NT; ++pb) pt = fmaf(U[pa * NB + pb][t], xb[pb], pt);
         pt = row_sum_f32(pt);
+#if MO_F32_RHS_VECTOR
+        vt[t] = rp[16 * pa + 4 * g + t] - pt;
+#else
         vt[t] = row_bcast_f32<0>(U[pa * NB + NR][t]) - pt;
+#endif
       }
       float q = 0.0f;
 #pragma unroll

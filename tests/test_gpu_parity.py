@@ -57,18 +57,22 @@ def batch_to_device(hb, dt=torch.float64):
 
 # Disagreements with the oracle are counted per TEST (a sweep calls solves_agree_or_knife_edge once per shape with a handful of problems):
 # every one of them needs its logged knife edge, a single call may hold at most one, and over a whole test they may not exceed 5 %.
-_TALLY = {"off": set(), "all": set()}   # distinct problems (a test may hold several kernels to the oracle on the same problems)
+# A disagreement whose closest decision sat on a NUMERICALLY SINGULAR reduced KKT matrix -- its condition-aware threshold 16 eps cond(K) >= 1:
+# rounding alone moves the Newton direction by its own size, the oracle's trajectory is one sample of noise -- is tallied apart: it cannot be
+# charged to the kernel, but a test may not live on such problems either (at most a third of its problems; each is logged as "singular").
+_TALLY = {"off": set(), "singular": set(), "all": set()}   # distinct problems (a test may hold several kernels to the oracle on the same problems)
 
 
 @pytest.fixture(autouse=True)
 def _knife_edge_budget():
-    _TALLY["off"], _TALLY["all"] = set(), set()
+    _TALLY["off"], _TALLY["singular"], _TALLY["all"] = set(), set(), set()
     yield
-    off, total = len(_TALLY["off"]), len(_TALLY["all"])
+    off, sing, total = len(_TALLY["off"]), len(_TALLY["singular"]), len(_TALLY["all"])
     if total >= 20:
         assert off <= 0.05 * total, f"{off} of {total} problems of this test have a Solve that differs from the oracle (each on a knife edge, but more than 5 %)"
     else:
         assert off <= 1, f"{off} of {total} problems of this test have a Solve that differs from the oracle"
+    assert 3 * sing <= total, f"{sing} of {total} problems of this test are excused by a numerically singular KKT matrix: the test does not pin the kernel"
 
 
 KNIFE_EDGE_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "qp_disagreements.jsonl")
@@ -80,12 +84,13 @@ def solves_agree_or_knife_edge(tag, make_qp, kw, runs):
     accepted on a problem where one decision of the ORACLE's run sat nearer to its threshold than the knife-edge threshold of its kind --
     also when the oracle ends in MAX_ITERATIONS (no blanket exemption: the device must then end there too, or show the knife edge).
     Every accepted disagreement is logged to gpurun_out/qp_disagreements.jsonl; over a whole test at most 5 % of the Solves may be such
-    cases (fixture _knife_edge_budget).  Returns the mask of problems on which all runs agree with the oracle."""
+    cases (fixture _knife_edge_budget) -- those whose knife edge is a numerically singular KKT matrix (threshold 16 eps cond(K) >= 1) are
+    tallied apart, at most a third of a test's problems.  Returns the mask of problems on which all runs agree with the oracle."""
     from oracle import margins as M
     labels = list(runs)
     B = len(runs[labels[0]][0])
     agree = np.ones(B, dtype=bool)
-    rows = []
+    rows, sing_idx = [], []
     for p in range(B):
         term, n_it, _, marg = M.solve_with_margins(make_qp(p), **kw)
         off = [l for l in labels if int(runs[l][0][p]) != term or int(runs[l][1][p]) != n_it]
@@ -93,8 +98,11 @@ def solves_agree_or_knife_edge(tag, make_qp, kw, runs):
             continue
         agree[p] = False
         ratio, where = M.closeness(marg)
+        singular = bool(where is not None and len(where) > 3 and where[3] >= 1.0)
         rows.append({"test": str(tag), "problem": int(p), "oracle": [int(term), int(n_it)], "runs": {l: [int(runs[l][0][p]), int(runs[l][1][p])] for l in labels},
-                     "closest_decision": list(where) if where else None, "margin_over_threshold": ratio})
+                     "closest_decision": list(where) if where else None, "margin_over_threshold": ratio, "singular": singular})
+        if singular:
+            sing_idx.append(int(p))
         assert ratio < 1.0, (f"{tag}: problem {p}: " + ", ".join(f"{l} ends ({int(runs[l][0][p])}, {int(runs[l][1][p])})" for l in labels)
                              + f", the oracle ({term}, {n_it}) with no decision near its threshold (closest: {where}, {ratio:.3g} x the knife-edge threshold)")
     if rows:
@@ -103,7 +111,9 @@ def solves_agree_or_knife_edge(tag, make_qp, kw, runs):
             for row in rows:
                 f.write(json.dumps(row) + "\n")
     base = str(tuple(tag)[:5]) if isinstance(tag, tuple) else str(tag)   # (the budget is per test: the _knife_edge_budget fixture)
-    _TALLY["all"].update((base, p) for p in range(B)); _TALLY["off"].update((base, int(p)) for p in np.flatnonzero(~agree))
+    _TALLY["all"].update((base, p) for p in range(B))
+    _TALLY["off"].update((base, int(p)) for p in np.flatnonzero(~agree) if int(p) not in sing_idx)
+    _TALLY["singular"].update((base, p) for p in sing_idx)
     return agree
 
 

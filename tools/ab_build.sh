@@ -8,7 +8,7 @@ src=$root/mini_opt_amd/csrc
 make -s -C "$src" -j8
 tmp=$(mktemp -d)
 objs=""
-for f in mo_api kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_ny34 kkt_fused_mc4 kkt_fused_tiny kkt_fused_f32 nls_kernels; do
+for f in mo_api eig_kernels kkt_generic kkt_fused kkt_fused_gather kkt_fused_ny2 kkt_fused_ny34 kkt_fused_mc4 kkt_fused_tiny kkt_fused_f32 nls_kernels; do
   rebuilt=0
   for g in "$@"; do [ "$g" = "$f.hip" ] && rebuilt=1; done
   if [ $rebuilt = 1 ]; then

@@ -79,10 +79,8 @@ int main(int argc, char** argv) {
     double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)h[i];
     printf("n=%d batch=%zu: %.3f ms (%.2f M steps/s, stamped build), status ok %zu/%zu, waves %llu\n", n, batch, ms, batch / ms / 1e3, okc, batch, h[8]);
     if (true) { printf("generic kernel\n"); }
-    for (int i = 0; i < 7; ++i) printf("  %-30s %9.0f ticks/problem/wave  %5.1f %%\n", names[i], (double)h[i] / batch, 100.0 * h[i] / tot);
-    printf("  wave lifetime: max %llu min %llu cycles; mean realtime %.1f us, max %.1f us (100 MHz ticks) => shader clock %.2f GHz\n", h[9], h[10],
-           h[11] / (double)h[8] / 100.0, h[12] / 100.0, (tot / h[8]) / (h[11] / (double)h[8] / 100.0) / 1e3);
-    printf("  total %.0f ticks per problem per wave (s_memtime ticks: 100 MHz constant clock => x ~21 for core cycles)\n", tot / batch);
+    for (int i = 0; i < 7; ++i) printf("  %-30s %9.0f ticks/problem  %5.1f %%\n", names[i], (double)h[i] / batch, 100.0 * h[i] / tot);
+    printf("  total %.0f ticks per problem (s_memtime; on this pool it counts close to core cycles: total x problems per workgroup / launch time)\n", tot / batch);
   }
   unsigned long long nd[16];
   CK(hipMemcpyFromSymbol(nd, HIP_SYMBOL(mo::g_nd_stamps), sizeof(nd)));
