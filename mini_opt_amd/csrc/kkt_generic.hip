@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
   int n = a.n, k = a.k, m = a.m, m_r = a.m_r;
   if constexpr (LARGE) carve_large(w, smem, (T*)a.H_work + (size_t)blockIdx.x * (size_t)a.H_work_stride, n, k, m, m_r);
   else carve(w, smem, n, k, m, m_r);
-  const int tid = threadIdx.x;
+  const int tid0 = threadIdx.x;
   const bool j_level = a.J != nullptr;
 
 #ifdef MO_GENERIC_STAMPS
@@ -1574,13 +1574,13 @@ __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(con
   for (long long p = blockIdx.x; p < a.batch; p += gridDim.x) {
     if (MODE == MODE_SOLVE && a.skip && a.skip[p * a.skip_stride] >= 0) continue;  // uniform: finished in the caller's outer loop
     __syncthreads();  // previous problem's readers are done with LDS
-    if constexpr (LARGE) {
-      // The sizes are the same for every problem, and LLVM knows it: it hoisted every scalar that depends only on them -- the tile masks of
-      // each J^T J block, panel widths, loop bounds, hundreds of them -- out of this loop, where they stayed live across all phases: 1 100
-      // SGPR spills to VGPR lanes, and the VGPRs holding those lanes spilled to scratch in turn (each reload a vmcnt(0) wait behind the other
-      // workgroup's memory traffic).  Opaque copies per problem: the scalars are recomputed where they are used.
-      asm volatile("" : "+s"(n), "+s"(k), "+s"(m), "+s"(m_r));
-    }
+    // The sizes are the same for every problem, and LLVM knows it: it hoisted every scalar that depends only on them -- the tile masks of
+    // each J^T J block, panel widths, loop bounds, hundreds of them -- and every predicate of the thread index out of this loop, where they
+    // stayed live across all phases: 1 100 SGPR spills to VGPR lanes in the LARGE kernels, and the VGPRs holding those lanes spilled to
+    // scratch in turn (each reload a vmcnt(0) wait behind the other workgroup's memory traffic).  Opaque copies per problem: the scalars are
+    // recomputed where they are used (the LARGE phases take a fresh copy of the thread index themselves).
+    asm volatile("" : "+s"(n), "+s"(k), "+s"(m), "+s"(m_r));
+    const int tid = opaque(tid0);
     const int V = n + 2 * m + k;
     const T* Jp = j_level ? (const T*)a.J + p * a.J_stride : nullptr;
     const T* rp = j_level ? (const T*)a.r + p * a.r_stride : nullptr;
