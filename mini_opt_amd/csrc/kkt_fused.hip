@@ -2509,9 +2509,10 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   a.stagger = env_stagger >= 0 ? (env_stagger & 0xff) : (headline_shape ? 4 : 0);
   a.chain_prio = env_stagger >= 0 ? ((env_stagger >> 8) & 1) : (headline_shape ? 1 : 0);   // MO_FUSED_STAGGER = units + 256 * priority
   // Waves per SIMD the kernel is register-budgeted for (defaults picked from measurements; MO_FUSED_WPS in -DMO_TUNING builds).
-  // measured best: 3 (A/B in DESIGN.md; round 3: a fourth wave per SIMD on the 32 grid for batches of 3 072 < B <= 4 096 -- one round instead of
-  // two for a third of the waves -- is 10 % SLOWER at BASELINE configs[1]: 0.136 vs 0.123 ms)
-  const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 4 ? 4 : 3);
+  // 64 grid: 3 (A/B in DESIGN.md).  32 grid: FOUR since round 4 (the kernel needs 100 VGPRs).  Round 3 had measured a fourth wave 10 % slower at
+  // BASELINE configs[1] (0.136 vs 0.123 ms) -- when launches still took a ticket per problem; with static rounds it is faster at every batch
+  // size: configs[1] 86.4 / 87.1 -> 94.9 / 96.4 M steps/s (4 096 problems are ONE round of 4 096 waves), batch 65 536: 140.6 -> 152.9 M.
+  const int wps = a.n > 32 ? (env_wps == 2 ? 2 : 3) : (env_wps == 3 ? 3 : 4);
   const int sw = (env_sw >= 0 && env_sw <= 6) ? env_sw : 3;
   long long grid = num_cus;  // one workgroup of 4*wps waves per CU; problems are pulled from the ticket counter
   const long long blocks_needed = (a.batch + 3) / 4;
@@ -2646,15 +2647,15 @@ hipError_t launch_fused(const KernelArgs& a_in, int, int num_cus, hipStream_t st
   }
   const dim3 gd((unsigned)grid), bd(256 * wps);
 #ifndef MO_TUNING
-  // The product build carries ONE instantiation per tile grid and input level: three waves per SIMD, the lean sweep (SW = 3).  The other
+  // The product build carries ONE instantiation per tile grid and input level: three waves per SIMD (four on the 32 grid), the lean sweep (SW = 3).  The other
   // waves-per-SIMD / sweep flavours DESIGN.md section 8 measured and rejected are instantiated in -DMO_TUNING builds only.
   (void)sw;
   if (a.n > 32) {
     if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, false>), gd, bd, 0, stream, a);
     else hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, true>), gd, bd, 0, stream, a);
   } else {
-    if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, false>), gd, bd, 0, stream, a);
-    else hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, true>), gd, bd, 0, stream, a);
+    if (a.J) hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 4, 3, false>), gd, bd, 0, stream, a);
+    else hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 4, 3, true>), gd, bd, 0, stream, a);
   }
   return hipGetLastError();
 #else
