@@ -1205,6 +1205,45 @@ def test_large_fp64_plan_runs_on_both_kernel_families():
     np.testing.assert_allclose(c.cpu().numpy(), np.einsum("bqi,bq->bi", J, r), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("n,k,zero_rows", [(200, 6, (4, 5)), (230, 40, (38, 39)), (200, 6, (2,)), (230, 40, (17,))],
+                         ids=["trailing_short_panel", "trailing_in_a_16_column_panel", "middle_short_panel", "middle_of_a_panel"])
+def test_large_generic_path_zero_pivot_rules(n, k, zero_rows):
+    """The register panels of the LARGE factorisation (round 4) carry no zero-pivot logic: a zero pivot raises a flag every wave sees alike and
+    the half panel is redone by the LDS loop that knows the rules (kkt_generic.hip, left_factor_half).  Zero rows of A_eq make exact zero
+    pivots in the y block.  TRAILING zero rows are what LDLT tolerates in natural order too (zero pivot, zero column below, nothing
+    behind it): status OK, the multiplier's direction comes out as D^+ leaves it, and the step must match the oracle's.  A zero row with
+    non-zero pivots behind it is a failure of the natural-order factorisation: that problem alone reports FACTORIZATION_FAILED, its
+    neighbours in the batch are untouched."""
+    rng = np.random.default_rng(n + k + len(zero_rows))
+    B, m, m_r = 4, 12, n + 10
+    J = rng.uniform(-1, 1, (B, m_r, n)); r = rng.uniform(-1, 1, (B, m_r))
+    A = rng.uniform(-1, 1, (B, n, k)); b = rng.uniform(-1, 1, (B, k))
+    bad = 2                                                    # the problem with the zero rows
+    for q in zero_rows:
+        A[bad, :, q] = 0.0; b[bad, q] = 0.0
+    cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0], (B, m)); cb = rng.uniform(0.5, 2.0, (B, m))
+    x = rng.uniform(-0.1, 0.1, (B, n)); sl = rng.uniform(0.2, 1.5, (B, m)); z = rng.uniform(0.1, 2, (B, m)); y = rng.uniform(-1, 1, (B, k))
+    vars_ = np.concatenate([x, sl, y, z], axis=1); mu = np.full(B, 0.05)
+    prob = Q.BatchedQP(n=n, k=k, m=m, J=T(J), r=T(r), lam=1e-3, A_eq=T(A), b_eq=T(b), cons_var=T(cv, torch.int32), cons_a=T(ca), cons_b=T(cb))
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.step_kernel() == "generic"
+    s.SetVariables(T(vars_))
+    delta, alpha, status = s.NewtonStep(T(mu), 0.995)
+    st = status.cpu().numpy(); d = delta.cpu().numpy()
+    ref, ref_alpha, ref_status, _ = orc.batched_newton_step(n, k, m, J=J, r=r, lam=1e-3, A_eq=A, b_eq=b, cons_var=cv, cons_a=ca, cons_b=cb, vars_=vars_, mu=mu)
+    others = [p for p in range(B) if p != bad]
+    assert np.all(st[others] == 0) and np.all(ref_status[others] == 0)
+    assert rel_inf_rows(d[others], ref[others]).max() < TOL64
+    trailing = min(zero_rows) == k - len(zero_rows)
+    if trailing:
+        assert st[bad] == 0 and ref_status[bad] == 0, (st[bad], ref_status[bad])
+        assert rel_inf_rows(d[bad:bad + 1], ref[bad:bad + 1]).max() < TOL64
+        np.testing.assert_allclose(alpha.cpu().numpy()[bad], ref_alpha[bad], atol=1e-9)
+    else:
+        assert st[bad] == L.MO_STATUS_FACTORIZATION_FAILED, st[bad]
+        assert np.all(np.isnan(d[bad]))
+
+
 @pytest.mark.parametrize("n,k,m,m_r,level,dt", [(256, 40, 128, 300, "J", torch.float64), (256, 40, 128, 0, "QP", torch.float64), (200, 0, 30, 210, "J", torch.float64),
                                                 (160, 50, 0, 170, "J", torch.float64), (300, 20, 64, 310, "J", torch.float32), (130, 70, 17, 0, "QP", torch.float64),
                                                 # shapes at the edges of the matrix-core J^T J / register-panel code (round 3): three rows of J (less than the four one
