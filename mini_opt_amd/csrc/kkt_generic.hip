@@ -2071,7 +2071,14 @@ size_t generic_lds_bytes(const KernelArgs& a, int elem_size) {
 
 // The LDS-resident kernel takes n + k <= 192 (the register-distributed factorisation: 16 x 16 threads x 12 x 12 blocks) whose workspace
 // fits the 160 KiB of a CU; everything beyond runs with H in a global workspace (LARGE).
-bool generic_needs_large(const KernelArgs& a, int elem_size) { return a.n + a.k > 192 || generic_lds_bytes(a, elem_size) > 160 * 1024; }
+// Systems of at least this size take the LARGE path (H in the plan's global workspace) although the LDS-resident kernel covers n + k <= 192
+// where H fits the LDS: since round 4 LARGE is the faster kernel from n + k = 72 on (one box, batch 65 536 / 16 384; LDS-resident vs LARGE:
+// n + k = 56: 7.84 vs 5.38 M steps/s, 64: 5.72 vs 5.21 M, 72 (BASELINE configs[2] shape): 2.86 vs 3.87 M, 130 (n = 90, k = 40): 0.61 vs
+// 1.86 M, Solve 92.9 k vs 229 k/s) -- two workgroups per CU whatever the size, matrix-core J^T J, no barrier per pivot.
+#ifndef MO_LARGE_MIN_P
+#define MO_LARGE_MIN_P 72
+#endif
+bool generic_needs_large(const KernelArgs& a, int elem_size) { return a.n + a.k >= MO_LARGE_MIN_P || generic_lds_bytes(a, elem_size) > 160 * 1024; }
 size_t generic_large_lds_bytes(const KernelArgs& a, int elem_size) {
   const int nb_cols = panel_cols_for(a.n, a.k, a.m, a.m_r, elem_size);
   if (nb_cols == 0) return (size_t)1 << 30;   // not even the vectors and an 8-column panel fit
@@ -2154,6 +2161,15 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
     if (e != hipSuccess) return e;                                                                                           \
     hipLaunchKernelGGL((kkt_generic_kernel<TYPE, MODE_, TG_, R_>), dim3((unsigned)grid), dim3(threads), lds, stream, a);      \
   } while (0)
+// (n + k >= MO_LARGE_MIN_P = 72 went to launch_generic_large above: the 16 x 16 grids with 9 and 12 blocks per thread of rounds 2 - 3 are
+// only instantiated where the knob keeps larger systems on the LDS-resident kernel)
+#if MO_LARGE_MIN_P <= 81
+#define MO_LAUNCH_FACTORISING(TYPE, MODE_)                     \
+  do {                                                         \
+    if (threads == 64) MO_LAUNCH_GENERIC(TYPE, MODE_, 8, 6);   \
+    else MO_LAUNCH_GENERIC(TYPE, MODE_, 16, 5);                \
+  } while (0)
+#else
 #define MO_LAUNCH_FACTORISING(TYPE, MODE_)                     \
   do {                                                         \
     if (threads == 64) MO_LAUNCH_GENERIC(TYPE, MODE_, 8, 6);   \
@@ -2161,6 +2177,7 @@ hipError_t launch_generic(const KernelArgs& a, int dtype, int num_cus, hipStream
     else if (P <= 144) MO_LAUNCH_GENERIC(TYPE, MODE_, 16, 9);  \
     else MO_LAUNCH_GENERIC(TYPE, MODE_, 16, 12);               \
   } while (0)
+#endif
 #define MO_DISPATCH_MODE(TYPE)                                          \
   switch (a.mode) {                                                     \
     case MODE_LINEARIZE: MO_LAUNCH_FACTORISING(TYPE, MODE_LINEARIZE); break;   \
