@@ -345,9 +345,6 @@ __host__ __device__ inline int large_jtj_stride(int wc) { return wc + 16 + ((32 
 #ifndef MO_LARGE_TQ
 #define MO_LARGE_TQ 4
 #endif
-#ifndef MO_LARGE_TW
-#define MO_LARGE_TW 8   // 16 x 16 tiles of the trailing update a wave handles per round (its row strip x 16 MO_LARGE_TW columns)
-#endif
 #ifndef MO_LARGE_JPF
 #define MO_LARGE_JPF 2   // 4-row steps of J whose loads are issued together on the direct path (16 loads a lane at 2)
 #endif
@@ -1557,7 +1554,8 @@ __device__ MO_INLINE void update_state(const Ws<T>& w, int n, int k, int m, T ap
 // ---- the kernel ------------------------------------------------------------------------------------------------
 // TG x TG = the thread grid of the register-distributed factorisation (8 x 8: single-wave workgroups, 16 x 16: 256 threads),
 // R = ceil((n + k) / TG) blocks per thread and dimension (also the block count of the J^T J register tiling: n <= TG R).
-// LARGE: H in the workgroup's global workspace (a.H_work), blocked factorisation, 96-wide J^T J super-blocks: any n + k the LDS vectors allow.
+// LARGE: H in the workgroup's global workspace (a.H_work), left-looking blocked factorisation, 128-wide J^T J super-blocks: any n + k the LDS
+// vectors allow, and every system of at least MO_LARGE_MIN_P.
 template <typename T, int MODE, int TG, int R, bool LARGE = false>
 __global__ __launch_bounds__(TG * TG, LARGE ? 2 : 1) void kkt_generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2092,7 +2090,8 @@ int generic_large_grid(const KernelArgs& a, int elem_size, int num_cus) {
   const size_t lds = generic_large_lds_bytes(a, elem_size);
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
+  if (per_cu > 2) per_cu = 2;   // the kernel is register-budgeted for two workgroups per CU (__launch_bounds__(256, 2)): more would only queue,
+                                // and every workgroup of the grid owns a slot of the plan's H workspace (n + k = 72: 46 KB each)
   return num_cus * per_cu;
 }
 
