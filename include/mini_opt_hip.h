@@ -83,7 +83,7 @@ typedef struct {
   uint32_t flags; /* MO_PLAN_* */
   int32_t reserved;
   int64_t max_batch; /* sizes plan-owned scratch: the (G, c) of mo_qp_solve with J-level input on the generic kernel; beyond the
-                        LDS-resident range (n + k > 192, or the system exceeds 160 KiB of LDS) also the number of H workspaces
+                        LDS-resident range of the generic kernel (n + k >= 72 since round 4) also the number of H workspaces
                         mo_plan_create allocates (0: one per workgroup of the full persistent grid) */
 } mo_plan_desc;
 
