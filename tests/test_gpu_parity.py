@@ -1250,12 +1250,16 @@ def test_large_generic_path_zero_pivot_rules(n, k, zero_rows):
                                                 # MFMA consumes), n + k just beyond 192, three full 128-wide super-blocks with two rows per thread in the panel, a first
                                                 # panel of more than 512 rows (LDS panel path) followed by register panels, fp32 with a ragged second super-block
                                                 (145, 0, 0, 3, "J", torch.float64), (190, 3, 2, 193, "J", torch.float64), (384, 16, 32, 390, "J", torch.float64),
-                                                (520, 8, 16, 64, "J", torch.float64), (260, 0, 10, 270, "J", torch.float32)],
-                         ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP", "n145_three_rows", "n190_k3", "n384", "n520_short_J", "n260_f32"])
+                                                (520, 8, 16, 64, "J", torch.float64), (260, 0, 10, 270, "J", torch.float32),
+                                                # (round 4) a system so large that only 8 panel columns fit the LDS beside its vectors: the left-looking
+                                                # update then runs in 8-column blocks whose finished columns are not a multiple of 16 (the tail loop)
+                                                (960, 8, 16, 0, "J", torch.float64)],
+                         ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP", "n145_three_rows", "n190_k3", "n384", "n520_short_J", "n260_f32",
+                              "n960_panel8"])
 def test_sizes_beyond_every_lds_resident_kernel(n, k, m, m_r, level, dt):
     """The reference resizes its solver to any N, K (qp.cc:36-48).  Beyond the fused kernels (n <= 128, k <= 31) and the LDS-resident generic
-    kernel (n + k <= 192, H in LDS) the generic kernel keeps H in a global workspace of its workgroup: blocked right-looking LDL^T (column
-    panels staged in LDS, rank-32 trailing updates), 96-wide J^T J super-blocks.  Step (with and without inequalities), KKT residual,
+    kernel (n + k <= 71 since round 4) the generic kernel keeps H in a global workspace of its workgroup: left-looking blocked LDL^T (half
+    panels staged in LDS and factorised in registers), 128-wide J^T J super-blocks on the matrix cores.  Step (with and without inequalities), KKT residual,
     Iterate and the whole Solve against the oracle: directions within 1e-10 rel-inf, Solve iteration-exact (fp32: against the oracle on
     fp32-rounded inputs at fp32 tolerances)."""
     rng = np.random.default_rng(n + 7 * k + m)
