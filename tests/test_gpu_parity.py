@@ -1253,9 +1253,11 @@ def test_large_generic_path_zero_pivot_rules(n, k, zero_rows):
                                                 (520, 8, 16, 64, "J", torch.float64), (260, 0, 10, 270, "J", torch.float32),
                                                 # (round 4) a system so large that only 8 panel columns fit the LDS beside its vectors: the left-looking
                                                 # update then runs in 8-column blocks whose finished columns are not a multiple of 16 (the tail loop)
-                                                (960, 8, 16, 0, "J", torch.float64)],
+                                                (960, 8, 16, 0, "J", torch.float64),
+                                                # mid-size systems the LARGE path serves since n + k >= 72 goes there: k beyond the fused kernels, both precisions
+                                                (90, 40, 17, 100, "J", torch.float64), (90, 40, 17, 100, "J", torch.float32), (60, 12, 300, 0, "QP", torch.float64)],
                          ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP", "n145_three_rows", "n190_k3", "n384", "n520_short_J", "n260_f32",
-                              "n960_panel8"])
+                              "n960_panel8", "n90_k40", "n90_k40_f32", "n60_m300_QP"])
 def test_sizes_beyond_every_lds_resident_kernel(n, k, m, m_r, level, dt):
     """The reference resizes its solver to any N, K (qp.cc:36-48).  Beyond the fused kernels (n <= 128, k <= 31) and the LDS-resident generic
     kernel (n + k <= 71 since round 4) the generic kernel keeps H in a global workspace of its workgroup: left-looking blocked LDL^T (half
