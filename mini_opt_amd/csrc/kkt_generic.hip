@@ -859,15 +859,18 @@ __device__ MO_INLINE int factor_in_registers(const Ws<T>& w, int P, int tid) {
 // registers by v_readlane -- scalars -- where the previous version published column j through LDS and waited for a workgroup barrier 16
 // times per half panel.  Same arithmetic (one IEEE division per pivot, the same products in the same order).  The zero-pivot rules are
 // NOT here: a zero (or NaN) pivot only raises a flag -- every wave sees the same pivots, so the flag needs no exchange -- and the function
-// then returns false having written nothing; the caller repeats the panel with the LDS loop that knows Eigen's rules (left_factor_half).
+// then writes nothing but that flag (w.iflag[4]); the caller repeats the panel with the LDS loop that knows Eigen's rules (left_factor_half).
 // (The first cut had the rules in the loop: their branches cost a copy of the register panel at every join, then scratch reloads of spilled
 // SGPRs behind vmcnt(0) in every pivot -- 3 k cycles per pivot, more than the barriers it had replaced.)
 // Leaves W = L D in H and in the LDS panel (for the second half of the outer block), 1 / D in invd.
+// A wave without a row of the panel (rows <= 64 x its index: the later panels of every system, most panels of a mid-size one) skips the
+// loop altogether; the verdict travels through w.iflag[4] (wave 0 always owns rows) and is read behind the caller's barrier.
 template <typename T, int NBR, int RPT>
-__device__ inline bool factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd, int rows, int ldp, int tid) {
+__device__ inline void factor_panel_regs(const Ws<T>& w, T* panel, int kb, int wd, int rows, int ldp, int tid) {
   T a[RPT][NBR], t[NBR];
   tid = opaque(tid);
-  const int lane = tid & 63;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool owns = 64 * wave < rows;   // (wave-uniform; with RPT = 2 the second row of a thread lies 256 further down)
 #ifdef MO_GENERIC_STAMPS
   const unsigned long long fp_ta = __builtin_amdgcn_s_memtime();
 #endif
@@ -875,13 +878,14 @@ __device__ inline bool factor_panel_regs(const Ws<T>& w, T* panel, int kb, int w
   for (int e = 0; e < RPT; ++e) {
     const int i = tid + 256 * e;
 #pragma unroll
-    for (int jj = 0; jj < NBR; ++jj) a[e][jj] = (i < rows && jj < wd && i >= jj) ? panel[i + (size_t)jj * ldp] : (T)0;
+    for (int jj = 0; jj < NBR; ++jj) a[e][jj] = (owns && i < rows && jj < wd && i >= jj) ? panel[i + (size_t)jj * ldp] : (T)0;
   }
   // (a ragged last panel, wd < NBR: the missing columns are identity columns -- pivot 1, multipliers 0 -- so that the pivot loop has no
   // condition on wd)
 #pragma unroll
-  for (int jj = 0; jj < NBR; ++jj) t[jj] = (lane < wd && jj <= lane) ? panel[lane + (size_t)jj * ldp] : ((lane == jj && lane < NBR) ? (T)1 : (T)0);
+  for (int jj = 0; jj < NBR; ++jj) t[jj] = (owns && lane < wd && jj <= lane) ? panel[lane + (size_t)jj * ldp] : ((lane == jj && lane < NBR) ? (T)1 : (T)0);
   __syncthreads();   // every wave has its copy of the diagonal block before any wave overwrites the LDS panel with W
+  if (!owns) return; // (wave-uniform)
 #ifdef MO_GENERIC_STAMPS
   const unsigned long long fp_t0 = __builtin_amdgcn_s_memtime();
   if (tid == 0) atomicAdd(&g_nd_stamps[9], fp_t0 - fp_ta);
@@ -913,7 +917,8 @@ __device__ inline bool factor_panel_regs(const Ws<T>& w, T* panel, int kb, int w
   if (tid == 0) atomicAdd(&g_nd_stamps[7], fp_t1 - fp_t0);
   if (tid == 0 && uni((int)bad)) atomicAdd(&g_nd_stamps[8], 1ull);
 #endif
-  if (uni((int)bad)) return false;
+  if (tid == 0) w.iflag[4] = bad ? 1 : 0;
+  if (uni((int)bad)) return;
   if (tid < wd) w.invd[kb + tid] = invs;
 #pragma unroll
   for (int e = 0; e < RPT; ++e) {
@@ -930,7 +935,6 @@ __device__ inline bool factor_panel_regs(const Ws<T>& w, T* panel, int kb, int w
 #ifdef MO_GENERIC_STAMPS
   if (tid == 0) atomicAdd(&g_nd_stamps[10], __builtin_amdgcn_s_memtime() - fp_t1);
 #endif
-  return true;
 }
 // LARGE: LEFT-LOOKING blocked LDL^T with H in global memory (round 4; same natural order, same zero-pivot rules, same result layout: W = L D
 // below the diagonal, invd = 1 / D).  Round 3 was right-looking -- after every 16-column panel the whole trailing matrix was read, updated and
@@ -1077,11 +1081,10 @@ __device__ inline int left_factor_half(const Ws<T>& w, T* panel, int kb, int wd,
   int status = MO_STATUS_OK;
   tid = opaque(tid);
   if (uni((int)kThreads) == 256 && rows <= 512 && !uni((int)found_zero)) {
-    bool done;
-    if (rows <= 256) done = factor_panel_regs<T, 16, 1>(w, panel, kb, wd, rows, ldp, tid);
-    else done = factor_panel_regs<T, 16, 2>(w, panel, kb, wd, rows, ldp, tid);
+    if (rows <= 256) factor_panel_regs<T, 16, 1>(w, panel, kb, wd, rows, ldp, tid);
+    else factor_panel_regs<T, 16, 2>(w, panel, kb, wd, rows, ldp, tid);
     __syncthreads();                                                             // the LDS copy of W is read by other threads
-    if (done) return status;
+    if (!uni(w.iflag[4])) return status;
     // (a zero or NaN pivot in this half panel: nothing was written; the loop below applies the rules)
   }
   for (int j = 0; j < wd; ++j) {                                                 // any size: the panel stays in LDS
