@@ -142,3 +142,83 @@ def test_random_shapes_solve_and_iterate_against_the_oracle(seed):
         with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_soak.txt"), "a") as f:
             f.write(dis[family].report() + "\n")    # the soak record (profiles/r04_fuzz_soak.txt): every disagreement with its margin
         assert len(dis[family].items) <= 0.05 * dis[family].total, dis[family].report()
+
+
+@pytest.mark.parametrize("seed", [21, 22] + EXTRA_SEEDS)
+def test_random_shapes_on_the_large_path(seed):
+    """Random systems of n + k >= 72 that only the generic kernel takes (more equalities than the fused kernels hold, or more than 128 / 256
+    inequality entries, or n > 128) -- since round 4 all of them on the LARGE path (H in the plan's global workspace, kkt_generic.hip):
+    ragged super-blocks of J^T J, block columns of every width, half panels with one to four waves owning rows, both input levels, every
+    layout of J, both precisions.  Step against the oracle (1e-10 rel-inf in fp64; fp32 on fp32-rounded inputs at its tolerance), the KKT
+    residual, and in fp64 the whole Solve: (termination, iterations) under the knife-edge rule of oracle/margins.py."""
+    rng = np.random.default_rng(seed)
+    from oracle import margins as M
+    dis = M.Disagreements(f"fuzz seed {seed}, LARGE path Solve")
+    for trial in range(14):
+        kind = int(rng.integers(0, 3))
+        if kind == 0:      # more equalities than the fused kernels hold beyond n = 64 (k > 31)
+            n = int(rng.integers(65, 129)); k = int(rng.integers(32, min(n // 2 + 1, 81))); m = int(rng.integers(0, 65))
+        elif kind == 1:    # many inequality entries
+            n = int(rng.integers(72, 129)); k = int(rng.integers(0, 17)); m = int(rng.integers(257, 400))
+        else:              # beyond the tile grids
+            n = int(rng.integers(129, 330)); k = int(rng.integers(0, min(n // 2, 70))); m = int(rng.integers(0, 130))
+        m_r = int(rng.integers(n, n + 40)); B = 3
+        f32 = bool(rng.integers(0, 4) == 0)
+        dt = torch.float32 if f32 else torch.float64
+        f = (lambda a_: a_.astype(np.float32).astype(np.float64)) if f32 else (lambda a_: a_)
+        level = rng.choice(["J", "QP"]); layout = int(rng.integers(0, 3)) if level == "J" else 0
+        J = f(rng.uniform(-1, 1, (B, m_r, n))); r = f(rng.uniform(-1, 1, (B, m_r)))
+        A = f(rng.uniform(-1, 1, (B, n, k)))
+        cv = rng.integers(0, n, (B, m)).astype(np.int32); ca = rng.choice([-1.0, 1.0, 2.0], (B, m))
+        x0 = rng.uniform(-0.5, 0.5, (B, n)); b = f(-np.einsum("bik,bi->bk", A, x0))
+        cb = f(-ca * np.take_along_axis(x0, cv.astype(np.int64), axis=1) + rng.uniform(0.05, 0.5, (B, m)))
+        lam = float(np.float32(0.05))
+        G = f(np.einsum("bqi,bqj->bij", J, J) + lam * np.eye(n)); c = f(np.einsum("bqi,bq->bi", J, r))
+        x = f(rng.uniform(-0.1, 0.1, (B, n))); sl = f(rng.uniform(0.2, 1.5, (B, m))); z = f(rng.uniform(0.1, 2, (B, m))); y = f(rng.uniform(-1, 1, (B, k)))
+        vars_ = np.concatenate([x, sl, y, z], axis=1); mu = np.full(B, float(np.float32(0.05)))
+        common = dict(A_eq=T(A, dt) if k else None, b_eq=T(b, dt) if k else None, cons_var=T(cv, torch.int32) if m else None,
+                      cons_a=T(ca, dt) if m else None, cons_b=T(cb, dt) if m else None)
+        kwj = {}
+        if level == "J":
+            if layout == 0: Jt = T(J, dt)
+            elif layout == 1:
+                wide = np.full((B, m_r, n + 3), 9.9); wide[:, :, :n] = J; Jt = T(wide, dt)
+            else:
+                colw = np.full((B, n, m_r + 2), -9.9); colw[:, :, :m_r] = J.transpose(0, 2, 1); Jt = T(colw, dt); kwj = dict(J_layout="col", J_rows=m_r)
+            prob = Q.BatchedQP(n=n, k=k, m=m, J=Jt, r=T(r, dt), lam=lam, **common, **kwj)
+        else:
+            prob = Q.BatchedQP(n=n, k=k, m=m, G=T(np.tril(G).transpose(0, 2, 1), dt), c=T(c, dt), **common)
+        tag = (seed, trial, n, k, m, m_r, str(level), layout, "f32" if f32 else "f64")
+        s = Q.QPInteriorPointSolver(prob)
+        assert s.step_kernel() == "generic", (tag, s.step_kernel())
+        s.SetVariables(T(vars_, dt))
+        delta, alpha, status = s.NewtonStep(T(mu, dt), 0.995)
+        assert torch.all(status == 0), tag
+        # the oracle works on the matrix the device forms: J^T J + lambda I of the (rounded) J for J-level input, the given G otherwise
+        Gl = np.stack([np.tril(J[p].T @ J[p] + lam * np.eye(n)) for p in range(B)]) if level == "J" else np.tril(G)
+        cl = np.einsum("bqi,bq->bi", J, r) if level == "J" else c
+        qps = []
+        for p in range(B):
+            qp = orc.QP(G=Gl[p], c=cl[p], A_eq=A[p].T if k else None, b_eq=b[p] if k else None, cons_var=cv[p], cons_a=ca[p], cons_b=cb[p])
+            qps.append(qp)
+            o = orc.Solver(qp)
+            st, d_ref, a_ref = o.newton_step(vars_[p], mu[p] if m else 0.0, 0.995, True)
+            assert st == 0, tag
+            got = delta[p].double().cpu().numpy()
+            err = np.abs(got - d_ref).max() / np.abs(d_ref).max()
+            assert err < (1e-10 if not f32 else 2e-3), (tag, p, err)
+        if f32:
+            continue
+        kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12,
+                  initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED if k else Q.NAIVE)
+        out = s.Solve(Q.Params(**kw))
+        assert torch.all(out.status == 0), tag
+        for p in range(B):
+            term, n_it, _, marg = M.solve_with_margins(qps[p], **kw)
+            same = int(out.termination_state[p]) == term and int(out.num_iterations[p]) == n_it
+            dis.check((tag, p, int(out.termination_state[p]), int(out.num_iterations[p]), (term, n_it)), same, None if same else marg)
+    print(dis.report())
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz_soak.txt"), "a") as fh:
+        fh.write(dis.report() + "\n")
+    assert len(dis.items) <= max(1, 0.05 * dis.total), dis.report()
