@@ -2454,8 +2454,10 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.mode == MODE_RESIDUAL && !a.r_out) return false;
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.m < 0) return false;
-  if (a.k > 31) {  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31, three / four (kkt_fused_ny34.hip) up to 47 / 63 on the 32 / 64 grids
-    if (a.k > 63 || a.n > 64 || a.m > 128) return false;
+  if (a.k > 31) {  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31, three / four (kkt_fused_ny34.hip) up to 47 / 63 on the 32 / 64 grids,
+                   // three on the 96 grid (round 4: 45 live tiles, as many as the 128 grid with one y tile)
+    if (a.k > 63 || a.n > 96 || a.m > 128) return false;
+    if (a.n > 64 && a.k > 47) return false;
     if (a.mode == MODE_LINEARIZE) return false;
     if (a.J && (fused_needs_gather(a) || (a.n & 1))) return false;  // packed even-n J or (G, c) only
   }
