@@ -2455,9 +2455,9 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.n < 2 || a.n > 128) return false;  // padded to 32 / 64 / 96 / 128 variables inside the kernel
   if (a.m < 0) return false;
   if (a.k > 31) {  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31, three / four (kkt_fused_ny34.hip) up to 47 / 63 on the 32 / 64 grids,
-                   // three on the 96 grid (round 4: 45 live tiles, as many as the 128 grid with one y tile)
-    if (a.k > 63 || a.n > 96 || a.m > 128) return false;
-    if (a.n > 64 && a.k > 47) return false;
+                   // and since round 4 three / four on the 96 grid (45 / 55 live tiles) and three on the 128 grid (66: it spills, and is still 2 x the generic kernel)
+    if (a.k > 63 || a.m > 128) return false;
+    if (a.n > 96 && a.k > 47) return false;      // (the 128 grid with four y tiles would be 78 live tiles)
     if (a.mode == MODE_LINEARIZE) return false;
     if (a.J && (fused_needs_gather(a) || (a.n & 1))) return false;  // packed even-n J or (G, c) only
   }

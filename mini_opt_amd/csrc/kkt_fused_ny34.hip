@@ -2,7 +2,7 @@
 // constraints on the 32- and 64-variable tile grids (the reference puts no limit on the number of equality rows, qp.cc:36-48; beyond these
 // shapes the generic kernel takes over).  Every y tile but the last is a full 16-pivot tile of the Schur complement; the last holds the
 // remaining rows and the right-hand side in index 15.  (NT + NY)(NT + NY + 1) / 2 live tiles: 15 / 21 on the 32 grid (three / two waves per
-// SIMD), 28 / 36 on the 64 grid (one wave per SIMD), 45 on the 96 grid with three y tiles (round 4: 32 <= k <= 47 up to n = 96).  Packed even-n J or (G, c) input, m <= 128 (two constraint slots per lane).
+// SIMD), 28 / 36 on the 64 grid (one wave per SIMD), 45 / 55 on the 96 grid, 66 on the 128 grid with three (round 4: k <= 63 up to n = 96, k <= 47 up to n = 128).  Packed even-n J or (G, c) input, m <= 128 (two constraint slots per lane).
 #define MO_FUSED_IMPL_ONLY
 #include "kkt_fused.hip"
 
@@ -22,8 +22,11 @@ hipError_t launch_fused_ny34(const KernelArgs& a, int num_cus, hipStream_t strea
     if (!a.J) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, true, 2, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a);      \
     else hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, 2, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a);          \
   } while (0)
-  if (huge) {
-    if (solve) MO_NY34(kkt_fused_solve_kernel, 6, 1, 3); else MO_NY34(kkt_fused_f64_kernel, 6, 1, 3);
+  if (a.n > 96) {          // the 128 grid: three y tiles only (fused_supported)
+    if (solve) MO_NY34(kkt_fused_solve_kernel, 8, 1, 3); else MO_NY34(kkt_fused_f64_kernel, 8, 1, 3);
+  } else if (huge) {       // the 96 grid
+    if (solve) { if (four) MO_NY34(kkt_fused_solve_kernel, 6, 1, 4); else MO_NY34(kkt_fused_solve_kernel, 6, 1, 3); }
+    else { if (four) MO_NY34(kkt_fused_f64_kernel, 6, 1, 4); else MO_NY34(kkt_fused_f64_kernel, 6, 1, 3); }
   } else if (solve) {
     if (big) { if (four) MO_NY34(kkt_fused_solve_kernel, 4, 1, 4); else MO_NY34(kkt_fused_solve_kernel, 4, 1, 3); }
     else { if (four) MO_NY34(kkt_fused_solve_kernel, 2, 2, 4); else MO_NY34(kkt_fused_solve_kernel, 2, 2, 3); }

@@ -156,8 +156,8 @@ def test_random_shapes_on_the_large_path(seed):
     dis = M.Disagreements(f"fuzz seed {seed}, LARGE path Solve")
     for trial in range(14):
         kind = int(rng.integers(0, 3))
-        if kind == 0:      # more equalities than the fused kernels hold on the 128 grid (k > 31; the 96 grid takes up to 47 since round 4)
-            n = int(rng.integers(97, 129)); k = int(rng.integers(32, min(n // 2 + 1, 81))); m = int(rng.integers(0, 65))
+        if kind == 0:      # more equalities than the fused kernels hold (since round 4: k <= 63 up to n = 96, k <= 47 up to n = 128)
+            n = int(rng.integers(100, 129)); k = int(rng.integers(48, min(n // 2 + 1, 81))); m = int(rng.integers(0, 65))
         elif kind == 1:    # many inequality entries
             n = int(rng.integers(72, 129)); k = int(rng.integers(0, 17)); m = int(rng.integers(257, 400))
         else:              # beyond the tile grids

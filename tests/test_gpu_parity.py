@@ -1132,7 +1132,9 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
                                              (96, 20, 32, 192, "J"), (128, 31, 64, 256, "J"), (128, 16, 30, 0, "QP"), (40, 16, 12, 80, "J"),
                                              (64, 31, 64, 128, "J"), (127, 17, 20, 130, "J"),
                                              # round 4: three y tiles on the 96 grid (32 <= k <= 47 up to n = 96)
-                                             (96, 40, 32, 192, "J"), (80, 47, 20, 0, "QP"), (66, 32, 64, 140, "J"), (90, 36, 128, 100, "J")])
+                                             (96, 40, 32, 192, "J"), (80, 47, 20, 0, "QP"), (66, 32, 64, 140, "J"), (90, 36, 128, 100, "J"),
+                                             # ... four on the 96 grid (48 <= k <= 63), three on the 128 grid (32 <= k <= 47)
+                                             (96, 63, 32, 200, "J"), (70, 48, 20, 0, "QP"), (128, 47, 64, 256, "J"), (100, 32, 16, 0, "QP"), (128, 40, 128, 140, "J")])
 def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
     """The 96- and 128-variable tile grids of the fp64 fused kernels (sizes the LDS-resident generic kernel cannot hold at all once
     n + k > 141): Newton step against the oracle, and the whole Solve against the oracle's Solve."""
@@ -1257,9 +1259,9 @@ def test_large_generic_path_zero_pivot_rules(n, k, zero_rows):
                                                 # update then runs in 8-column blocks whose finished columns are not a multiple of 16 (the tail loop)
                                                 (960, 8, 16, 0, "J", torch.float64),
                                                 # mid-size systems the LARGE path serves since n + k >= 72 goes there: k beyond the fused kernels, both precisions
-                                                (90, 50, 17, 100, "J", torch.float64), (90, 40, 17, 100, "J", torch.float32), (60, 12, 300, 0, "QP", torch.float64)],
+                                                (90, 70, 17, 100, "J", torch.float64), (90, 40, 17, 100, "J", torch.float32), (60, 12, 300, 0, "QP", torch.float64)],
                          ids=["n256_J", "n256_QP", "n200_no_eq", "n160_no_ineq", "n300_f32", "n130_k70_QP", "n145_three_rows", "n190_k3", "n384", "n520_short_J", "n260_f32",
-                              "n960_panel8", "n90_k50", "n90_k40_f32", "n60_m300_QP"])
+                              "n960_panel8", "n90_k70", "n90_k40_f32", "n60_m300_QP"])
 def test_sizes_beyond_every_lds_resident_kernel(n, k, m, m_r, level, dt):
     """The reference resizes its solver to any N, K (qp.cc:36-48).  Beyond the fused kernels (n <= 128, k <= 31) and the LDS-resident generic
     kernel (n + k <= 71 since round 4) the generic kernel keeps H in a global workspace of its workgroup: left-looking blocked LDL^T (half
