@@ -2463,8 +2463,9 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   }
   // up to four constraint slots per lane: m <= 256 (beyond 128, and beyond 64 for Solve / Iterate on the 96 / 128 grids: kkt_fused_mc4.hip)
   if (a.m > 256) return false;
-  if (a.m > 128 && (a.k > 15 || (a.J && (a.n & 1)))) return false;  // the two-y-tile and the flat-stream kernels carry at most two / one slot
-  if (a.k > 15 && a.m > 64 && a.n > 64 && a.mode != MODE_STEP) return false;  // two y tiles on the 96 / 128 grids: Solve / Iterate carry one slot
+  if (a.m > 128 && (a.k > 31 || (a.J && (a.n & 1)))) return false;  // three / four y tiles and the flat-stream kernels carry at most two / one slot
+  // (round 4: the two-y-tile kernels carry up to four slots on every grid, Solve / Iterate included -- a box on each of 128 variables
+  // beside 16 .. 31 equalities used to fall to the generic kernel)
   if (!a.ticket || !a.vars) return false;
   if (a.mode == MODE_STEP && !a.delta) return false;
   if (a.J) {  // J-level: 16-byte pieces of a packed row-major J (even n), the flat-group stream (odd n <= 64), or the gather stream

@@ -43,7 +43,22 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
     else if (gather) hipLaunchKernelGGL((kkt_fused_solve_kernel<NT_, WPS_, 3, false, 1, JMODE_GATHER, 2, PCK_>), gd, bd, 0, stream, a);  \
     else hipLaunchKernelGGL((kkt_fused_solve_kernel<NT_, WPS_, 3, false, MC_, JMODE_VECTOR, 2, PCK_>), gd, bd, 0, stream, a);            \
   } while (0)
-  if (solve) {  // two constraint slots per lane on the 32 / 64 grids only (fused_supported)
+  const bool four_slots = a.m > 128;   // (packed J or (G, c) only: fused_supported keeps the gather stream at m <= 64)
+  if (solve && four_slots) {
+    switch (grid_tile) {
+      case 2: MO_NY2(kkt_fused_solve_kernel, 2, 3, 4); break;
+      case 4: MO_NY2(kkt_fused_solve_kernel, 4, 2, 4); break;
+      case 6: MO_NY2(kkt_fused_solve_kernel, 6, 1, 4); break;
+      default: MO_NY2(kkt_fused_solve_kernel, 8, 1, 4); break;
+    }
+  } else if (!solve && four_slots) {
+    switch (grid_tile) {
+      case 2: MO_NY2(kkt_fused_f64_kernel, 2, 3, 4); break;
+      case 4: MO_NY2(kkt_fused_f64_kernel, 4, 2, 4); break;
+      case 6: MO_NY2(kkt_fused_f64_kernel, 6, 1, 4); break;
+      default: MO_NY2(kkt_fused_f64_kernel, 8, 1, 4); break;
+    }
+  } else if (solve) {
     switch (grid_tile) {
       case 2: if (pc) MO_NY2S(2, 3, 2, true); else MO_NY2S(2, 3, 2, false); break;
       case 4:
@@ -54,8 +69,8 @@ hipError_t launch_fused_ny2(const KernelArgs& a, int num_cus, hipStream_t stream
         if (one_slot) { if (pc) MO_NY2S(4, 2, 1, true); else MO_NY2S(4, 2, 1, false); }
         else { if (pc) MO_NY2S(4, 2, 2, true); else MO_NY2S(4, 2, 2, false); }
         break;
-      case 6: MO_NY2(kkt_fused_solve_kernel, 6, 1, 1); break;
-      default: MO_NY2(kkt_fused_solve_kernel, 8, 1, 1); break;
+      case 6: if (one_slot) MO_NY2(kkt_fused_solve_kernel, 6, 1, 1); else MO_NY2(kkt_fused_solve_kernel, 6, 1, 2); break;
+      default: if (one_slot) MO_NY2(kkt_fused_solve_kernel, 8, 1, 1); else MO_NY2(kkt_fused_solve_kernel, 8, 1, 2); break;
     }
   } else {
     switch (grid_tile) {
