@@ -2459,7 +2459,8 @@ bool fused_supported(const KernelArgs& a, int dtype) {
     if (a.k > 63 || a.m > 128) return false;
     if (a.n > 96 && a.k > 47) return false;      // (the 128 grid with four y tiles would be 78 live tiles)
     if (a.mode == MODE_LINEARIZE) return false;
-    if (a.J && (fused_needs_gather(a) || (a.n & 1))) return false;  // packed even-n J or (G, c) only
+    // (every layout of J since round 4: the gather instantiations of kkt_fused_ny34.hip, one constraint slot per lane -- m <= 64 below)
+    if (a.J && (a.n & 1) && a.m > 64) return false;
   }
   // up to four constraint slots per lane: m <= 256 (beyond 128, and beyond 64 for Solve / Iterate on the 96 / 128 grids: kkt_fused_mc4.hip)
   if (a.m > 256) return false;

@@ -1709,7 +1709,9 @@ def _layouts_of(J):
 
 
 @pytest.mark.parametrize("n,k,m,m_r", [(64, 8, 32, 128), (32, 4, 16, 64), (40, 3, 10, 50), (63, 8, 32, 131), (96, 8, 40, 192), (101, 5, 20, 203),
-                                       (128, 10, 40, 256), (6, 2, 4, 9), (48, 20, 10, 70), (33, 31, 16, 41), (100, 16, 30, 150)])
+                                       (128, 10, 40, 256), (6, 2, 4, 9), (48, 20, 10, 70), (33, 31, 16, 41), (100, 16, 30, 150),
+                                       # round 4: three / four y tiles in every layout
+                                       (64, 40, 32, 128), (57, 33, 20, 70), (96, 50, 24, 192), (128, 36, 16, 260), (30, 20, 8, 64)])
 def test_fused_kernels_take_every_layout_of_J(n, k, m, m_r):
     """Column-major J, a leading dimension beyond n, rows that are only 8-byte aligned, odd n beyond 64: all of them run on the fused
     kernels (the gather stream, kkt_fused_gather.hip) and give the packed layout's results -- step against the oracle, Iterate, Solve and
