@@ -2456,7 +2456,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   if (a.m < 0) return false;
   if (a.k > 31) {  // one y tile up to k = 15, two (kkt_fused_ny2.hip) up to 31, three / four (kkt_fused_ny34.hip) up to 47 / 63 on the 32 / 64 grids,
                    // and since round 4 three / four on the 96 grid (45 / 55 live tiles) and three on the 128 grid (66: it spills, and is still 2 x the generic kernel)
-    if (a.k > 63 || a.m > 128) return false;
+    if (a.k > 63) return false;                  // (m <= 256 as everywhere since round 4: four constraint slots per lane beyond 128)
     if (a.n > 96 && a.k > 47) return false;      // (the 128 grid with four y tiles would be 78 live tiles)
     if (a.mode == MODE_LINEARIZE) return false;
     // (every layout of J since round 4: the gather instantiations of kkt_fused_ny34.hip, one constraint slot per lane -- m <= 64 below)
@@ -2464,7 +2464,7 @@ bool fused_supported(const KernelArgs& a, int dtype) {
   }
   // up to four constraint slots per lane: m <= 256 (beyond 128, and beyond 64 for Solve / Iterate on the 96 / 128 grids: kkt_fused_mc4.hip)
   if (a.m > 256) return false;
-  if (a.m > 128 && (a.k > 31 || (a.J && (a.n & 1)))) return false;  // three / four y tiles and the flat-stream kernels carry at most two / one slot
+  if (a.m > 128 && a.J && (a.n & 1)) return false;  // the flat-stream kernels carry one slot
   // (round 4: the two-y-tile kernels carry up to four slots on every grid, Solve / Iterate included -- a box on each of 128 variables
   // beside 16 .. 31 equalities used to fall to the generic kernel)
   if (!a.ticket || !a.vars) return false;

@@ -2,7 +2,7 @@
 // constraints on the 32- and 64-variable tile grids (the reference puts no limit on the number of equality rows, qp.cc:36-48; beyond these
 // shapes the generic kernel takes over).  Every y tile but the last is a full 16-pivot tile of the Schur complement; the last holds the
 // remaining rows and the right-hand side in index 15.  (NT + NY)(NT + NY + 1) / 2 live tiles: 15 / 21 on the 32 grid (three / two waves per
-// SIMD), 28 / 36 on the 64 grid (one wave per SIMD), 45 / 55 on the 96 grid, 66 on the 128 grid with three (round 4: k <= 63 up to n = 96, k <= 47 up to n = 128).  Packed even-n J or (G, c) input with m <= 128 (two constraint slots per lane); any other layout of J through the gather
+// SIMD), 28 / 36 on the 64 grid (one wave per SIMD), 45 / 55 on the 96 grid, 66 on the 128 grid with three (round 4: k <= 63 up to n = 96, k <= 47 up to n = 128).  Packed even-n J or (G, c) input with m <= 256 (two constraint slots per lane, four beyond 128: round 4); any other layout of J through the gather
 // stream with m <= 64 (round 4).
 #define MO_FUSED_IMPL_ONLY
 #include "kkt_fused.hip"
@@ -20,9 +20,13 @@ hipError_t launch_fused_ny34(const KernelArgs& a, int num_cus, hipStream_t strea
   const dim3 gd((unsigned)grid), bd(256 * wps);
   // J-level input: 16-byte pieces of a packed row-major J, or the per-lane gather stream for every other layout (odd n included; m <= 64)
   const bool gather = a.J && (fused_needs_gather(a) || (a.n & 1));
+  const bool four_slots = a.m > 128;   // (packed J or (G, c): fused_supported keeps the gather stream at m <= 64)
 #define MO_NY34(KERNEL, NT_, WPS_, NY_)                                                                          \
   do {                                                                                                           \
-    if (!a.J) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, true, 2, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a);      \
+    if (four_slots) {                                                                                            \
+      if (!a.J) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, true, 4, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a);    \
+      else hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, 4, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a);        \
+    } else if (!a.J) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, true, 2, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a); \
     else if (gather) hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, 1, JMODE_GATHER, NY_>), gd, bd, 0, stream, a); \
     else hipLaunchKernelGGL((KERNEL<NT_, WPS_, 3, false, 2, JMODE_VECTOR, NY_>), gd, bd, 0, stream, a);          \
   } while (0)

@@ -1137,7 +1137,9 @@ def _fused_vs_generic_case(rng, level, n, k, m, m_r, feasible=False, kkt_tol=1e-
                                              (96, 63, 32, 200, "J"), (70, 48, 20, 0, "QP"), (128, 47, 64, 256, "J"), (100, 32, 16, 0, "QP"), (128, 40, 128, 140, "J"),
                                              # ... and two y tiles with up to four constraint slots per lane on every grid (a box on each variable beside 16 .. 31 equalities)
                                              (128, 20, 256, 260, "J"), (100, 31, 200, 0, "QP"), (64, 24, 256, 128, "J"), (96, 16, 100, 192, "J"), (32, 16, 200, 64, "J"),
-                                             (128, 16, 128, 0, "QP")])
+                                             (128, 16, 128, 0, "QP"),
+                                             # ... and three / four y tiles with four slots (m up to 256 beside 32 .. 63 equalities)
+                                             (100, 40, 200, 210, "J"), (64, 63, 256, 0, "QP"), (96, 48, 150, 192, "J"), (30, 15, 60, 64, "J")])
 def test_fused_fp64_up_to_128_variables(n, k, m, m_r, level):
     """The 96- and 128-variable tile grids of the fp64 fused kernels (sizes the LDS-resident generic kernel cannot hold at all once
     n + k > 141): Newton step against the oracle, and the whole Solve against the oracle's Solve."""
