@@ -10,7 +10,9 @@ hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t str
   const bool solve = a.mode == MODE_SOLVE || a.mode == MODE_ITERATE || a.mode == MODE_RESIDUAL;
   const int grid_tile = a.n > 96 ? 8 : a.n > 64 ? 6 : a.n > 32 ? 4 : 2;
   // waves per SIMD: the register budgets of the fast-path instantiations
-  const int wps = solve ? (grid_tile == 2 ? 3 : grid_tile == 4 ? 2 : 1) : (grid_tile == 2 || grid_tile == 4 ? 3 : grid_tile == 6 ? 2 : 1);
+  // (the 32 grid's step kernel runs four waves per SIMD since round 4, as its packed sibling does: 105 VGPRs)
+  const bool step32 = !solve && a.mode != MODE_LINEARIZE && grid_tile == 2;
+  const int wps = solve ? (grid_tile == 2 ? 3 : grid_tile == 4 ? 2 : 1) : (step32 ? 4 : grid_tile == 2 || grid_tile == 4 ? 3 : grid_tile == 6 ? 2 : 1);
   long long grid = num_cus;
   const long long need = (a.batch + 3) / 4;
   if (grid > need) grid = need;
@@ -34,7 +36,7 @@ hipError_t launch_fused_gather(const KernelArgs& a, int num_cus, hipStream_t str
     }
   } else {
     switch (grid_tile) {
-      case 2: hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 3, 3, false, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((kkt_fused_f64_kernel<2, 4, 3, false, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;
       case 4: hipLaunchKernelGGL((kkt_fused_f64_kernel<4, 3, 3, false, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;
       case 6: hipLaunchKernelGGL((kkt_fused_f64_kernel<6, 2, 3, false, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;
       default: hipLaunchKernelGGL((kkt_fused_f64_kernel<8, 1, 3, false, 1, JMODE_GATHER>), gd, bd, 0, stream, a); break;
