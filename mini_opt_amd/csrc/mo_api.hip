@@ -296,6 +296,18 @@ int mo_plan_create(const mo_plan_desc* desc, mo_plan** out) {
     p->H_work_slot_bytes = slot_bytes;
     p->H_work_slots = slots;
   }
+  // Tile park of the fused fp64 Solve kernels beyond the 32 grid (qp_solve_impl): one slot per wave of the persistent grid (one workgroup
+  // per CU, at most twelve waves each), 22.5 KB at n = 64, 78 KB at n = 128.  Optional -- without it the kernels rebuild the tiles every
+  // pass -- so a failed allocation is not an error.
+  if (desc->dtype == MO_F64 && desc->n > 32 && desc->n <= 128 && desc->k <= 63 && desc->m <= 256) {
+    const int nt = desc->n > 96 ? 8 : desc->n > 64 ? 6 : 4;
+    const size_t per_slot = (size_t)(nt * (nt + 1) / 2) * 256 + (size_t)nt * 64;
+    const size_t slots = (size_t)p->num_cus * 12;
+    if (hipMalloc(&p->tile_scratch, slots * per_slot * p->elem) != hipSuccess) {
+      p->tile_scratch = nullptr;
+      (void)hipGetLastError();
+    }
+  }
 
   *out = p;
   return MO_OK;
@@ -561,16 +573,9 @@ int qp_solve_impl(mo_plan* plan, const mo_problem* prob, int64_t batch, const mo
     // Tile park of the fused Solve kernels: the G tiles a wave cannot keep in LDS between the passes go to a scratch indexed by the
     // wave's slot in the persistent grid (one workgroup per CU, at most twelve waves each), so its size does not depend on the batch
     // and the lines a wave re-reads every pass stay in its XCD's L2.  Optional: without it the kernel rebuilds the tiles every pass.
+    // Plan-owned: mo_plan_create allocates it (round 4; it used to be allocated by the first Solve -- an allocation in the launch path).
     const int nt = plan->desc.n > 96 ? 8 : plan->desc.n > 64 ? 6 : plan->desc.n > 32 ? 4 : 2;
     const size_t per_slot = (size_t)(nt * (nt + 1) / 2) * 256 + (size_t)nt * 64;
-    const size_t slots = (size_t)plan->num_cus * 12;
-    MO_HIP_CHECK(hipSetDevice(plan->desc.device));
-    if (!plan->tile_scratch) {
-      if (hipMalloc(&plan->tile_scratch, slots * per_slot * plan->elem) != hipSuccess) {
-        plan->tile_scratch = nullptr;
-        (void)hipGetLastError();
-      }
-    }
     a.G_out = plan->tile_scratch; a.G_out_stride = (long long)per_slot;
   }
   return launch_chosen(plan, a, choice, stream);  // fused Solve kernel (fp64: n <= 128; fp32: n = 64 / 128), generic kernel otherwise

@@ -1625,6 +1625,46 @@ def test_large_generic_workspace_belongs_to_the_plan():
         lib.mo_plan_destroy(plan)
 
 
+@pytest.mark.parametrize("cfg", ["cfg3", "n128"])
+def test_first_fused_solve_allocates_nothing(cfg):
+    """The tile park of the fused fp64 Solve kernels beyond the 32 grid (the G tiles a wave cannot keep in LDS between passes: 69 MB of
+    per-wave-slot scratch at n = 64, 239 MB at n = 128) belongs to the plan since round 4: mo_plan_create allocates it, the first
+    mo_qp_solve of a plan allocates nothing (it used to hipMalloc it in the launch path).  Device memory is flat over that first call."""
+    import ctypes as C
+    d = synth.CONFIGS["cfg3"] if cfg == "cfg3" else dict(n=128, k=14, m=64, m_r=256)
+    n, k, m, m_r, B = d["n"], d["k"], d["m"], d["m_r"], 96
+    hb = synth.make_batch(n, k, m, m_r, B, stream=17)
+    prob = batch_to_device(hb)
+    s = Q.QPInteriorPointSolver(prob)
+    assert s.solve_kernel().startswith("fused_solve"), s.solve_kernel()
+    s.SetVariables(T(hb.vars))
+    kw = dict(initial_mu=1.0, sigma=0.1, termination_kkt_tol=1e-8, max_iterations=12, initial_guess_method=Q.SOLVE_EQUALITY_CONSTRAINED)
+    sp = Q.Params(**kw).as_struct()
+    V = n + 2 * m + k
+    term = torch.zeros(B, dtype=torch.int32, device=dev()); nit = torch.zeros(B, dtype=torch.int32, device=dev())
+    its = torch.zeros(B, kw["max_iterations"], L.MO_ITER_RECORD, dtype=torch.float64, device=dev())
+    lag = torch.zeros(B, 2, dtype=torch.float64, device=dev()); status = torch.zeros(B, dtype=torch.int32, device=dev())
+    svars = s.variables()
+    lib, plan, ps = L.lib(), s._plan, s._prob
+    # (what the HIP runtime reserves on its own account happens on ANOTHER plan first: the module load of the process's first launch -- 256 MiB --
+    # and the scratch arena of a kernel with a private segment, 160 MB for the 128 grid's Solve)
+    warm = Q.QPInteriorPointSolver(batch_to_device(hb))
+    warm.SetVariables(T(hb.vars)); warm.Solve(Q.Params(**kw))
+    del warm
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    L.check(lib.mo_qp_solve(plan, C.byref(ps), B, C.byref(sp), Q._ptr(svars), V, Q._ptr(term), Q._ptr(nit), Q._ptr(its), Q._ptr(lag), Q._ptr(status),
+                            Q._stream()))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20), (free0, torch.cuda.mem_get_info()[0])
+    assert torch.all(status == 0) and torch.all(term == Q.SATISFIED_KKT_TOL)
+    G = np.einsum("bqi,bqj->bij", hb.J, hb.J) + hb.lam * np.eye(n); c = np.einsum("bqi,bq->bi", hb.J, hb.r)
+    for p in range(0, B, 31):
+        o = orc.Solver(orc.QP(G=np.tril(G[p]), c=c[p], A_eq=hb.A_eq[p].T, b_eq=hb.b_eq[p], cons_var=hb.cons_var[p], cons_a=hb.cons_a[p], cons_b=hb.cons_b[p]))
+        t_ref, its_ref = o.solve(**kw)
+        assert int(term[p]) == t_ref and int(nit[p]) == len(its_ref), (p, int(nit[p]), len(its_ref))
+
+
 @pytest.mark.parametrize("batch", [1, 2, 13])
 def test_tiny_batches_on_the_fused_kernels(batch):
     """Fewer problems than waves in one workgroup: the ticket loop must hand out exactly `batch` problems (step, Solve, linearise)."""
